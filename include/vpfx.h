@@ -1,0 +1,195 @@
+/*
+ * vpfx.h -- C ABI of libvpfx: the MI355X-native sparse-volumetric-particle hot path
+ * (particle binning -> FillVolume + light propagation -> RayMarch + inter-metavoxel blend).
+ *
+ * This is the drop-in boundary for the path that, in the reference
+ * (rajabala/Volumetric-Particles-For-Unity, file = Assets/Main Scene/VolumetricParticleRenderer.cs,
+ * "VPR.cs" below), is driven by VolumetricParticleRenderer.OnPostRender (VPR.cs:181-220).
+ * The reference has no native boundary (no DllImport anywhere); the calls being replaced are the
+ * Unity Graphics calls of that path.  Each entry point cites the reference code it replaces.
+ *
+ * Conventions (same as the reference):
+ *   - every float[16] is a Unity Matrix4x4 in memory order = COLUMN-major (m00,m10,m20,m30,m01,...);
+ *     vectors are column vectors (HLSL mul(M,v), Fill.shader:106).
+ *   - metavoxel ("MV") arrays are indexed [zz][yy][xx] (VPR.cs:287); zz = 0 is nearest the light.
+ *   - a brick (one MV's 3D texture, RenderTextureFormat.ARGBHalf, VPR.cs:312) is
+ *     [slice][py][px][rgba] IEEE binary16, rgb = lit colour, a = density.
+ *   - light-propagation / light-depth maps are [py + yy*nv][px + xx*nv] float32 (VPR.cs:259-275).
+ *   - images are [row][col][rgba] float32 premultiplied alpha, row 0 = bottom of the view.
+ *   - the caller owns every pointer it passes; the library copies during the call and keeps none.
+ *   - one context is NOT thread-safe; calls on one context must be serialised by the caller
+ *     (the reference calls everything from Unity's main thread).
+ *   - every function returns VP_OK (0) or a negative vp_status; no C++ exception crosses the ABI.
+ *     The reference logs and carries on (Debug.LogError, VPR.cs:352,790); callers may do the same.
+ *   - there is NO CPU fallback: without a HIP device vp_create fails with VP_ERR_NO_DEVICE.
+ */
+#ifndef VPFX_H
+#define VPFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPFX_ABI_VERSION 1
+
+typedef enum vp_status {
+    VP_OK = 0,
+    VP_ERR_BAD_ARG = -1,     /* null pointer / out-of-range value                               */
+    VP_ERR_HIP = -2,         /* a HIP runtime call failed; see vp_last_error                    */
+    VP_ERR_OOM = -3,         /* device or host allocation failed                                */
+    VP_ERR_STATE = -4,       /* call order violated (e.g. raymarch before fill)                 */
+    VP_ERR_NO_DEVICE = -5,   /* no HIP device visible (there is no CPU fallback)                */
+    VP_ERR_UNSUPPORTED = -6  /* configuration outside what the kernels are built for            */
+} vp_status;
+
+typedef struct vp_ctx vp_ctx;
+
+/* Grid / screen configuration.  Counterpart of the inspector fields VPR.cs:82-86 and of
+ * CreateResources (VPR.cs:224-281).  Metavoxels are cubes (the reference assumes it, VPR.cs:422). */
+typedef struct vp_config {
+    int32_t num_mv[3];        /* numMetavoxelsX, Y, Z                                  VPR.cs:83 */
+    int32_t num_voxels;       /* numVoxelsInMetavoxel (nv): 8, 16, 32 or 64            VPR.cs:85 */
+    int32_t num_border;       /* numBorderVoxels per end                               VPR.cs:86 */
+    float   mv_scale;         /* mvScale.x: world size of one metavoxel                VPR.cs:84 */
+    int32_t width, height;    /* Screen.width / height (particlesRT extent)            VPR.cs:228 */
+    int32_t device;           /* HIP device ordinal, -1 = current device                          */
+    int32_t slab_z0, slab_z1; /* owned light-axis slab zz in [z0,z1); 0,0 = whole grid (1 GPU)    */
+    int32_t reserved[5];
+} vp_config;
+
+/* Byte layout of one caller-side particle record (ParticleSystem.Particle[], VPR.cs:412-413).
+ * Offsets are explicit because the managed struct layout is Unity-version specific. */
+typedef struct vp_particle_layout {
+    int32_t stride;               /* bytes per record                                             */
+    int32_t off_position;         /* 3 x f32, particle-system local space       .position :418    */
+    int32_t off_size;             /* f32, diameter                              .size     :425    */
+    int32_t off_rotation;         /* f32                                        .rotation :583    */
+    int32_t off_lifetime;         /* f32, remaining seconds                     .lifetime :586    */
+    int32_t off_start_lifetime;   /* f32                                        .startLifetime    */
+    int32_t rotation_in_radians;  /* 0: degrees (the C# property), 1: radians (the raw field)     */
+    int32_t reserved;
+} vp_particle_layout;
+
+/* Uniforms of the fill pass: SetFillPassConstants (VPR.cs:523-554). */
+typedef struct vp_fill_params {
+    float   opacity_factor;       /* _OpacityFactor                                               */
+    float   displacement_scale;   /* _DisplacementScale                                           */
+    int32_t fade_out_particles;   /* _FadeOutParticles                                            */
+    float   ambient[3];           /* _AmbientColor                                                */
+    float   init_light_intensity; /* _InitLightIntensity (reference passes 1.0)                   */
+    float   light_near, light_far;/* light camera clip planes (0.3 / 1000, VPR.cs:340-342)        */
+    float   light_cam_distance;   /* light camera sits gridCenter - fwd*200 (VPR.cs:365)          */
+    int32_t cubemap_size;         /* S: edge of one displacement cubemap face                     */
+    int32_t reserved;
+    const float* cubemap;         /* 6*S*S f32 = .x channel of _DisplacementTexture; faces in D3D
+                                     order +X,-X,+Y,-Y,+Z,-Z; row 0 = top; bilinear, clamp        */
+    const float* light_depth_map; /* optional [(Ny*nv)][(Nx*nv)] f32 in [0,1] (_LightDepthMap,
+                                     D3D ortho depth); NULL = 1.0 everywhere (no occluders)       */
+} vp_fill_params;
+
+/* Main camera: SetRaymarchPassConstants (VPR.cs:733-737) + RenderMetavoxel (VPR.cs:778). */
+typedef struct vp_camera {
+    float world_to_camera[16];    /* Camera.worldToCameraMatrix (view space looks down -Z)        */
+    float camera_to_world[16];    /* Camera.cameraToWorldMatrix                                   */
+    float cam_pos[3];             /* Camera.main.transform.position                               */
+    float fov_y;                  /* vertical field of view in RADIANS (_Fov)                     */
+    float near_clip, far_clip;    /* clip planes used by the rasteriser coverage rule             */
+} vp_camera;
+
+typedef struct vp_raymarch_params {
+    int32_t steps_per_mv;         /* rayMarchSteps (_NumRaymarchStepsPerMV)                       */
+    int32_t soft_distance;        /* softParticleStepDistance (_SoftDistance)                     */
+    const float* scene_depth;     /* optional [H][W] f32 linear eye depth of opaque scene for the
+                                     ZTest Less rejection (RM.shader:14); NULL = no occluders     */
+    int32_t reserved[4];
+} vp_raymarch_params;
+
+typedef struct vp_stats {
+    int64_t particles;            /* particles uploaded                                           */
+    int64_t occupied_mv;          /* numMetavoxelsCovered (VPR.cs:515), within the owned slab     */
+    int64_t pairs;                /* sum over MVs of mParticlesCovered.Count                      */
+    int64_t voxels_filled;        /* occupied_mv * nv^3                                           */
+    int64_t samples;              /* ray-march samples of the last vp_raymarch* call              */
+    int64_t brick_bytes;          /* resident brick pool bytes                                    */
+    int64_t max_pairs_per_mv;
+    int64_t reserved[5];
+} vp_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Start() + CreateResources (VPR.cs:132-149, 224-317). */
+int  vp_create(const vp_config* cfg, vp_ctx** out);
+void vp_destroy(vp_ctx* ctx);
+/* Message for the most recent failure on ctx (or on vp_create when ctx == NULL). */
+const char* vp_last_error(const vp_ctx* ctx);
+int  vp_abi_version(void);
+/* Run all device work of this context on the given hipStream_t (NULL = default stream). */
+int  vp_set_stream(vp_ctx* ctx, void* hip_stream);
+/* Block until all device work queued by this context has finished. */
+int  vp_sync(vp_ctx* ctx);
+
+/* ---- per-frame host logic ------------------------------------------------------------------- */
+/* UpdateMetavoxelPositions (VPR.cs:370-394).  light_to_world = dirLight.transform.localToWorldMatrix
+ * (rigid), grid_center = gridCenter.transform.position. */
+int  vp_set_frame(vp_ctx* ctx, const float light_to_world[16], const float grid_center[3]);
+
+/* BinParticlesToMetavoxels (VPR.cs:397-457) = vp_upload_particles + vp_bin_resident.
+ * `particles` is host memory (e.g. a pinned ParticleSystem.Particle[]). */
+int  vp_bin(vp_ctx* ctx, const void* particles, int32_t count, const vp_particle_layout* layout,
+            const float psys_local_to_world[16]);
+int  vp_upload_particles(vp_ctx* ctx, const void* particles, int32_t count,
+                         const vp_particle_layout* layout, const float psys_local_to_world[16]);
+int  vp_bin_resident(vp_ctx* ctx);
+
+/* FillMetavoxels / FillMetavoxel + FillVolume.shader (VPR.cs:495-609, Fill.shader:152-274). */
+int  vp_fill(vp_ctx* ctx, const vp_fill_params* params);
+
+/* RenderMetavoxels / RenderMetavoxel + RayMarchVoxel.shader + ROP blend
+ * (VPR.cs:613-794, RM.shader:14-18,95-302).  rgba_out = particlesRT as [H][W][4] f32.
+ * vp_raymarch synchronises and copies to host; the _device form writes device memory and is
+ * asynchronous on the context's stream. */
+int  vp_raymarch(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, float* rgba_out);
+int  vp_raymarch_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params,
+                        void* d_rgba_out);
+
+/* CompositeParticles.shader (Comp.shader:10, VPR.cs:210): scene.rgb = p.rgb + scene.rgb*(1-p.a),
+ * scene.a += p.a; in place on device images [H][W][4] f32. */
+int  vp_composite_device(vp_ctx* ctx, const void* d_particles_rgba, void* d_scene_rgba);
+
+/* ---- multi-GPU (one context per GPU, each owning a contiguous zz slab) ---------------------- */
+/* Fill split at the only cross-slab dependency, the per-column transmitted light (Fill.shader:224,250):
+ *   vp_fill_local   : density/ao of the slab + slab transmittance map tau (computed with T_in = 1)
+ *                     written to d_tau_out [(Ny*nv)][(Nx*nv)] f32 (device);
+ *   [caller all-gathers tau over RCCL and forms T_in = prod_{slabs before} tau]
+ *   vp_fill_finish  : propagate with the true incoming light d_light_in (device, same shape;
+ *                     NULL = 1.0) and store the bricks. */
+int  vp_fill_local(vp_ctx* ctx, const vp_fill_params* params, void* d_tau_out);
+int  vp_fill_finish(vp_ctx* ctx, const void* d_light_in);
+/* Partial images of the owned slab: d_over = composite of its MVs drawn in the OVER phase (zz <= zBoundary),
+ * d_under = composite of those in the UNDER phase; each [H][W][4] f32 device.  *phase_mask gets bit0 if
+ * the OVER image is non-empty, bit1 for UNDER. */
+int  vp_raymarch_partial_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params,
+                                void* d_over, void* d_under, int32_t* phase_mask);
+/* Ordered final blend of gathered partial images (VPR.cs:652-711 restricted to slab granularity):
+ * d_partials[i] (device pointers, host array) are applied in the given order, kinds[i] = 0 OVER, 1 UNDER. */
+int  vp_blend_partials_device(vp_ctx* ctx, const void* const* d_partials, const int32_t* kinds, int32_t n,
+                              void* d_rgba_out);
+/* zBoundary of RenderMetavoxels (VPR.cs:642-648) for this frame/camera. */
+int  vp_z_boundary(vp_ctx* ctx, const vp_camera* cam, int32_t* z_boundary);
+
+/* ---- parity probes / stats ------------------------------------------------------------------ */
+int  vp_get_mv_positions(vp_ctx* ctx, float* pos_out /* [Nz][Ny][Nx][3] */);
+int  vp_read_binlist(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz, int32_t* ids, int32_t cap, int32_t* n);
+int  vp_read_bincounts(vp_ctx* ctx, int32_t* counts /* [Nz][Ny][Nx] */);
+int  vp_read_brick(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz, uint16_t* half_rgba /* nv^3*4 */);
+int  vp_read_lightmap(vp_ctx* ctx, float* out /* [(Ny*nv)][(Nx*nv)] */);
+int  vp_get_stats(vp_ctx* ctx, vp_stats* out);
+/* Device time in milliseconds of the dominant kernel of a stage over its most recent launch,
+ * measured with HIP events on the context's stream. stage: 0 bin, 1 fill, 2 raymarch. */
+int  vp_last_kernel_ms(vp_ctx* ctx, int32_t stage, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPFX_H */

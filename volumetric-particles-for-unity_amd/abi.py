@@ -1,0 +1,111 @@
+"""ctypes mirror of include/vpfx.h (the C ABI structs).  Keep in lock-step with the header.
+
+The same Structures are passed to libvpfx (the product) and, in tests only, to the CPU oracle,
+whose entry points deliberately take the same structs.
+"""
+import ctypes as C
+
+VP_OK = 0
+VP_ERR_BAD_ARG = -1
+VP_ERR_HIP = -2
+VP_ERR_OOM = -3
+VP_ERR_STATE = -4
+VP_ERR_NO_DEVICE = -5
+VP_ERR_UNSUPPORTED = -6
+
+STATUS_NAMES = {
+    0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
+    -4: "VP_ERR_STATE", -5: "VP_ERR_NO_DEVICE", -6: "VP_ERR_UNSUPPORTED",
+}
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class vp_config(C.Structure):
+    _fields_ = [
+        ("num_mv", C.c_int32 * 3),
+        ("num_voxels", C.c_int32),
+        ("num_border", C.c_int32),
+        ("mv_scale", C.c_float),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("device", C.c_int32),
+        ("slab_z0", C.c_int32),
+        ("slab_z1", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class vp_particle_layout(C.Structure):
+    _fields_ = [
+        ("stride", C.c_int32),
+        ("off_position", C.c_int32),
+        ("off_size", C.c_int32),
+        ("off_rotation", C.c_int32),
+        ("off_lifetime", C.c_int32),
+        ("off_start_lifetime", C.c_int32),
+        ("rotation_in_radians", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class vp_fill_params(C.Structure):
+    _fields_ = [
+        ("opacity_factor", C.c_float),
+        ("displacement_scale", C.c_float),
+        ("fade_out_particles", C.c_int32),
+        ("ambient", C.c_float * 3),
+        ("init_light_intensity", C.c_float),
+        ("light_near", C.c_float),
+        ("light_far", C.c_float),
+        ("light_cam_distance", C.c_float),
+        ("cubemap_size", C.c_int32),
+        ("reserved", C.c_int32),
+        ("cubemap", c_float_p),
+        ("light_depth_map", c_float_p),
+    ]
+
+
+class vp_camera(C.Structure):
+    _fields_ = [
+        ("world_to_camera", C.c_float * 16),
+        ("camera_to_world", C.c_float * 16),
+        ("cam_pos", C.c_float * 3),
+        ("fov_y", C.c_float),
+        ("near_clip", C.c_float),
+        ("far_clip", C.c_float),
+    ]
+
+
+class vp_raymarch_params(C.Structure):
+    _fields_ = [
+        ("steps_per_mv", C.c_int32),
+        ("soft_distance", C.c_int32),
+        ("scene_depth", c_float_p),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class vp_stats(C.Structure):
+    _fields_ = [
+        ("particles", C.c_int64),
+        ("occupied_mv", C.c_int64),
+        ("pairs", C.c_int64),
+        ("voxels_filled", C.c_int64),
+        ("samples", C.c_int64),
+        ("brick_bytes", C.c_int64),
+        ("max_pairs_per_mv", C.c_int64),
+        ("reserved", C.c_int64 * 5),
+    ]
+
+
+# every symbol include/vpfx.h declares (checked by tests/test_abi.py against the built library)
+EXPORTED_SYMBOLS = [
+    "vp_create", "vp_destroy", "vp_last_error", "vp_abi_version", "vp_set_stream", "vp_sync",
+    "vp_set_frame", "vp_bin", "vp_upload_particles", "vp_bin_resident", "vp_fill",
+    "vp_raymarch", "vp_raymarch_device", "vp_composite_device",
+    "vp_fill_local", "vp_fill_finish", "vp_raymarch_partial_device", "vp_blend_partials_device",
+    "vp_z_boundary",
+    "vp_get_mv_positions", "vp_read_binlist", "vp_read_bincounts", "vp_read_brick",
+    "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",
+]
