@@ -114,7 +114,7 @@ class Oracle:
     def bin_list(self, xx, yy, zz, cap=1 << 16):
         ids = np.empty(cap, dtype=np.int32)
         n = C.c_int(0)
-        self._ck(self.L.vpo_read_binlist(self.h, xx, yy, zz, _fp(ids), cap, C.byref(n)), "vpo_read_binlist")
+        self._ck(self.L.vpo_read_binlist(self.h, int(xx), int(yy), int(zz), _fp(ids), cap, C.byref(n)), "vpo_read_binlist")
         return ids[: n.value].copy()
 
     def particle_records(self, count):
@@ -139,7 +139,7 @@ class Oracle:
 
     def read_brick(self, xx, yy, zz):
         out = np.empty((self.nv, self.nv, self.nv, 4), dtype=np.uint16)
-        self._ck(self.L.vpo_read_brick(self.h, xx, yy, zz, _fp(out)), "vpo_read_brick")
+        self._ck(self.L.vpo_read_brick(self.h, int(xx), int(yy), int(zz), _fp(out)), "vpo_read_brick")
         return out.view(np.float16)
 
     def read_lightmap(self):

@@ -1,0 +1,494 @@
+// api.cpp -- the C ABI of include/vpfx.h: argument checking, device-memory ownership, stage sequencing.
+// No compute happens on the host beyond the per-frame uniforms of host_logic.cpp; there is no CPU fallback.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "vpfx_internal.h"
+
+thread_local std::string g_vp_create_error;
+
+int vp_fail(vp_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_vp_create_error = buf;
+    return code;
+}
+
+namespace {
+
+template <typename T>
+int dev_alloc(vp_ctx* c, T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    VP_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return VP_OK;
+}
+
+int ensure_device(vp_ctx* c)
+{
+    VP_HIP(hipSetDevice(c->device));
+    return VP_OK;
+}
+
+size_t lightmap_elems(const vp_ctx* c) { return (size_t)c->g.Nx * c->g.nv * c->g.Ny * c->g.nv; }
+size_t image_elems(const vp_ctx* c) { return (size_t)c->cfg.width * c->cfg.height * 4; }
+size_t nv3(const vp_ctx* c) { return (size_t)c->g.nv * c->g.nv * c->g.nv; }
+
+int ensure_bricks(vp_ctx* c, bool need_scratch)
+{
+    const size_t need = (size_t)c->h_meta.occupied;
+    if (need > c->brick_cap) {
+        if (c->d_bricks) VP_HIP(hipFree(c->d_bricks));
+        c->d_bricks = nullptr;
+        c->brick_cap = 0;
+        const size_t cap = need + need / 8 + 16;
+        VP_HIP(hipMalloc((void**)&c->d_bricks, cap * nv3(c) * sizeof(uint2)));
+        c->brick_cap = cap;
+    }
+    if (need_scratch && need > c->dens_cap) {
+        if (c->d_dens_ao) VP_HIP(hipFree(c->d_dens_ao));
+        c->d_dens_ao = nullptr;
+        c->dens_cap = 0;
+        const size_t cap = need + need / 8 + 16;
+        VP_HIP(hipMalloc((void**)&c->d_dens_ao, cap * nv3(c) * sizeof(float2)));
+        c->dens_cap = cap;
+    }
+    return VP_OK;
+}
+
+// upload the fill pass inputs that live behind pointers (cubemap, light depth map) and build the uniforms
+int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
+{
+    if (p->cubemap) {
+        const int S = p->cubemap_size;
+        if (S < 1 || S > 4096) return vp_fail(c, VP_ERR_BAD_ARG, "cubemap_size %d out of range", S);
+        if (S != c->cubeS) {
+            if (c->d_cubequads) VP_HIP(hipFree(c->d_cubequads));
+            c->d_cubequads = nullptr;
+            VP_HIP(hipMalloc((void**)&c->d_cubequads, (size_t)6 * (S + 1) * (S + 1) * sizeof(float4)));
+            c->cubeS = S;
+        }
+        float* d_cube = nullptr;
+        const size_t bytes = (size_t)6 * S * S * sizeof(float);
+        VP_HIP(hipMalloc((void**)&d_cube, bytes));
+        hipError_t e = hipMemcpyAsync(d_cube, p->cubemap, bytes, hipMemcpyHostToDevice, c->stream);
+        int rc = VP_OK;
+        if (e == hipSuccess) rc = launch_build_cubequads(c, d_cube, S);
+        hipError_t e2 = hipStreamSynchronize(c->stream);       // the caller's cubemap pointer is not retained
+        (void)hipFree(d_cube);
+        if (e != hipSuccess || e2 != hipSuccess) return vp_fail(c, VP_ERR_HIP, "cubemap upload failed");
+        if (rc) return rc;
+    } else if (!c->d_cubequads) {
+        return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: no displacement cubemap given and none resident");
+    }
+    if (p->light_depth_map) {
+        if (!c->d_depthmap) { int rc = dev_alloc(c, &c->d_depthmap, lightmap_elems(c)); if (rc) return rc; }
+        VP_HIP(hipMemcpyAsync(c->d_depthmap, p->light_depth_map, lightmap_elems(c) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        VP_HIP(hipStreamSynchronize(c->stream));
+        c->have_depthmap = true;
+    } else {
+        c->have_depthmap = false;                               // NULL = no occluders (depth 1.0 everywhere)
+    }
+    hl_build_fill_consts(c, p);
+    return VP_OK;
+}
+
+int check_fill_ready(vp_ctx* c, const char* who)
+{
+    if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "%s before vp_set_frame", who);
+    if (!c->binned) return vp_fail(c, VP_ERR_STATE, "%s before vp_bin", who);
+    return VP_OK;
+}
+
+int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k)
+{
+    if (!cam || !rp) return vp_fail(c, VP_ERR_BAD_ARG, "null camera / params");
+    if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_raymarch before vp_fill");
+    if (rp->steps_per_mv < 1 || rp->soft_distance < 1) return vp_fail(c, VP_ERR_BAD_ARG, "steps_per_mv and soft_distance must be >= 1");
+    hl_build_rm_consts(c, cam, rp, k);
+    hl_build_rank(c, cam, c->h_rank);
+    VP_HIP(hipMemcpyAsync(c->d_rank, c->h_rank, (size_t)c->g.Nx * c->g.Ny * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (rp->scene_depth) {
+        if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
+        VP_HIP(hipMemcpyAsync(c->d_scene_depth, rp->scene_depth, (size_t)c->cfg.width * c->cfg.height * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    }
+    // h_rank / scene_depth are pageable: the async copies above have already consumed them on return
+    return VP_OK;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------------
+VP_EXPORT int vp_abi_version(void) { return VPFX_ABI_VERSION; }
+
+VP_EXPORT const char* vp_last_error(const vp_ctx* c) { return c ? c->err.c_str() : g_vp_create_error.c_str(); }
+
+VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
+{
+    vp_ctx* c = nullptr;
+    if (!cfg || !out) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: null argument");
+    *out = nullptr;
+    const int nv = cfg->num_voxels;
+    if (cfg->num_mv[0] < 1 || cfg->num_mv[1] < 1 || cfg->num_mv[2] < 1 || !(cfg->mv_scale > 0.f) || cfg->num_border < 0 ||
+        2 * cfg->num_border >= nv || cfg->width < 1 || cfg->height < 1)
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: bad grid/screen configuration");
+    if (nv != 16 && nv != 32 && nv != 64)
+        return vp_fail(nullptr, VP_ERR_UNSUPPORTED, "vp_create: num_voxels %d not built (16, 32, 64)", nv);
+    if ((size_t)cfg->num_mv[0] * cfg->num_mv[1] * cfg->num_mv[2] > ((size_t)1 << 28))
+        return vp_fail(nullptr, VP_ERR_UNSUPPORTED, "vp_create: grid too large");
+    int z0 = cfg->slab_z0, z1 = cfg->slab_z1;
+    if (z0 == 0 && z1 == 0) z1 = cfg->num_mv[2];
+    if (z0 < 0 || z1 > cfg->num_mv[2] || z0 >= z1) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: bad slab [%d,%d)", z0, z1);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return vp_fail(nullptr, VP_ERR_NO_DEVICE, "vp_create: no HIP device (%s); libvpfx has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: device %d of %d", dev, ndev);
+
+    c = new (std::nothrow) vp_ctx();
+    if (!c) return vp_fail(nullptr, VP_ERR_OOM, "vp_create: host allocation failed");
+    c->cfg = *cfg;
+    c->device = dev;
+    c->n3 = (size_t)cfg->num_mv[0] * cfg->num_mv[1] * cfg->num_mv[2];
+    // identity frame until vp_set_frame
+    memset(c->L, 0, sizeof c->L); c->L[0] = c->L[5] = c->L[10] = c->L[15] = 1.f;
+    c->h_mvPos = (float*)malloc(c->n3 * 3 * sizeof(float));
+    c->h_rank = (int*)malloc((size_t)cfg->num_mv[0] * cfg->num_mv[1] * sizeof(int));
+    int rc = VP_OK;
+    auto fail = [&](int code) { g_vp_create_error = c->err; vp_destroy(c); return code; };
+    if (!c->h_mvPos || !c->h_rank) { c->err = "vp_create: host allocation failed"; return fail(VP_ERR_OOM); }
+    hl_build_grid(c);
+    if ((rc = ensure_device(c))) return fail(rc);
+    const size_t nxy = (size_t)cfg->num_mv[0] * cfg->num_mv[1];
+    if ((rc = dev_alloc(c, &c->d_mvPos, c->n3 * 3)) || (rc = dev_alloc(c, &c->d_count, c->n3)) ||
+        (rc = dev_alloc(c, &c->d_offsets, c->n3 + 1)) || (rc = dev_alloc(c, &c->d_cursor, c->n3)) ||
+        (rc = dev_alloc(c, &c->d_brick_index, c->n3)) || (rc = dev_alloc(c, &c->d_occ_list, c->n3)) ||
+        (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
+        (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
+        (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)))
+        return fail(rc);
+    for (int s = 0; s < 3; ++s)
+        for (int j = 0; j < 2; ++j)
+            if (hipEventCreate(&c->ev[s][j]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(VP_ERR_HIP); }
+    *out = c;
+    return VP_OK;
+}
+
+VP_EXPORT void vp_destroy(vp_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
+                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_meta, c->d_bricks, c->d_dens_ao,
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_mvtrans, c->d_rank, c->d_image, c->d_scene_depth, c->d_samples};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    for (int s = 0; s < 3; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
+    free(c->h_mvPos); free(c->h_rank);
+    delete c;
+}
+
+VP_EXPORT int vp_set_stream(vp_ctx* c, void* hip_stream)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    c->stream = (hipStream_t)hip_stream;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_sync(vp_ctx* c)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_set_frame(vp_ctx* c, const float light_to_world[16], const float grid_center[3])
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!light_to_world || !grid_center) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_frame: null argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    memcpy(c->L, light_to_world, sizeof c->L);
+    memcpy(c->gc, grid_center, sizeof c->gc);
+    hl_build_grid(c);
+    VP_HIP(hipMemcpyAsync(c->d_mvPos, c->h_mvPos, c->n3 * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VP_HIP(hipStreamSynchronize(c->stream));
+    c->have_frame = true;
+    c->binned = c->filled = c->local_done = false;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_upload_particles(vp_ctx* c, const void* particles, int32_t count, const vp_particle_layout* lay,
+                                  const float psys_local_to_world[16])
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if ((!particles && count > 0) || count < 0 || !lay || !psys_local_to_world)
+        return vp_fail(c, VP_ERR_BAD_ARG, "vp_upload_particles: null/negative argument");
+    const int32_t offs[5] = {lay->off_position + 8, lay->off_size, lay->off_rotation, lay->off_lifetime, lay->off_start_lifetime};
+    if (lay->stride < 4) return vp_fail(c, VP_ERR_BAD_ARG, "vp_upload_particles: stride %d", lay->stride);
+    for (int32_t o : offs)
+        if (o < 0 || o + 4 > lay->stride) return vp_fail(c, VP_ERR_BAD_ARG, "vp_upload_particles: field offset outside the record");
+    if (lay->off_position < 0) return vp_fail(c, VP_ERR_BAD_ARG, "vp_upload_particles: field offset outside the record");
+    int rc = ensure_device(c); if (rc) return rc;
+    const size_t bytes = (size_t)count * lay->stride;
+    if (bytes > c->raw_cap) {
+        if (c->d_raw) VP_HIP(hipFree(c->d_raw));
+        c->d_raw = nullptr; c->raw_cap = 0;
+        VP_HIP(hipMalloc((void**)&c->d_raw, bytes + bytes / 4 + 256));
+        c->raw_cap = bytes + bytes / 4 + 256;
+    }
+    if (count > c->P_cap) {
+        if (c->d_ws) VP_HIP(hipFree(c->d_ws));
+        if (c->d_rec) VP_HIP(hipFree(c->d_rec));
+        c->d_ws = nullptr; c->d_rec = nullptr; c->P_cap = 0;
+        const int cap = count + count / 4 + 64;
+        VP_HIP(hipMalloc((void**)&c->d_ws, (size_t)cap * sizeof(float4)));
+        VP_HIP(hipMalloc((void**)&c->d_rec, (size_t)cap * 16 * sizeof(float)));
+        c->P_cap = cap;
+    }
+    c->P = count;
+    c->lay = *lay;
+    hl_build_psys(c, psys_local_to_world);
+    if (count > 0) {
+        VP_HIP(hipMemcpyAsync(c->d_raw, particles, bytes, hipMemcpyHostToDevice, c->stream));
+        rc = launch_extract(c); if (rc) return rc;
+        VP_HIP(hipStreamSynchronize(c->stream));               // caller's array is not retained past return
+    }
+    c->have_particles = true;
+    c->binned = c->filled = c->local_done = false;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_bin_resident(vp_ctx* c)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_bin before vp_set_frame");
+    if (!c->have_particles) return vp_fail(c, VP_ERR_STATE, "vp_bin_resident before vp_upload_particles");
+    int rc = ensure_device(c); if (rc) return rc;
+    rc = launch_bin(c); if (rc) return rc;
+    c->binned = true;
+    c->filled = c->local_done = false;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_bin(vp_ctx* c, const void* particles, int32_t count, const vp_particle_layout* lay, const float psys_local_to_world[16])
+{
+    int rc = vp_upload_particles(c, particles, count, lay, psys_local_to_world);
+    if (rc) return rc;
+    return vp_bin_resident(c);
+}
+
+VP_EXPORT int vp_fill(vp_ctx* c, const vp_fill_params* p)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!p) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: null params");
+    int rc = check_fill_ready(c, "vp_fill"); if (rc) return rc;
+    if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, false))) return rc;
+    rc = launch_fill(c, 0, nullptr, c->d_lightmap); if (rc) return rc;
+    c->filled = true;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_fill_local(vp_ctx* c, const vp_fill_params* p, void* d_tau_out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!p || !d_tau_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill_local: null argument");
+    int rc = check_fill_ready(c, "vp_fill_local"); if (rc) return rc;
+    if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, true))) return rc;
+    rc = launch_fill(c, 1, nullptr, (float*)d_tau_out); if (rc) return rc;
+    c->local_done = true;
+    c->filled = false;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_fill_finish(vp_ctx* c, const void* d_light_in)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!c->local_done) return vp_fail(c, VP_ERR_STATE, "vp_fill_finish before vp_fill_local");
+    int rc = ensure_device(c); if (rc) return rc;
+    rc = launch_fill(c, 2, (const float*)d_light_in, c->d_lightmap); if (rc) return rc;
+    c->filled = true;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_raymarch_device(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, void* d_rgba_out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!d_rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch_device: null output");
+    int rc = ensure_device(c); if (rc) return rc;
+    RmConsts k;
+    rc = stage_raymarch(c, cam, rp, &k); if (rc) return rc;
+    if (!rp->scene_depth) { /* no occluders */ }
+    float* keep = c->d_scene_depth;
+    if (!rp->scene_depth) c->d_scene_depth = nullptr;
+    rc = launch_raymarch(c, k, (float*)d_rgba_out, nullptr);
+    c->d_scene_depth = keep;
+    return rc;
+}
+
+VP_EXPORT int vp_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, float* rgba_out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch: null output");
+    int rc = vp_raymarch_device(c, cam, rp, c->d_image); if (rc) return rc;
+    VP_HIP(hipMemcpyAsync(rgba_out, c->d_image, image_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    VP_HIP(hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_raymarch_partial_device(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, void* d_over, void* d_under,
+                                         int32_t* phase_mask)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!d_over || !d_under) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch_partial_device: null output");
+    int rc = ensure_device(c); if (rc) return rc;
+    RmConsts k;
+    rc = stage_raymarch(c, cam, rp, &k); if (rc) return rc;
+    k.partial = 1;
+    if (phase_mask) {
+        // bit0: the slab has OVER-phase slices (zz <= zBoundary), bit1: UNDER-phase slices
+        *phase_mask = (k.z0 <= k.zB ? 1 : 0) | (k.z1 - 1 > k.zB ? 2 : 0);
+    }
+    float* keep = c->d_scene_depth;
+    if (!rp->scene_depth) c->d_scene_depth = nullptr;
+    rc = launch_raymarch(c, k, (float*)d_over, (float*)d_under);
+    c->d_scene_depth = keep;
+    return rc;
+}
+
+VP_EXPORT int vp_blend_partials_device(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int32_t n, void* d_rgba_out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!d_partials || !kinds || n < 0 || !d_rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_blend_partials_device: bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    return launch_blend(c, d_partials, kinds, n, (float*)d_rgba_out);
+}
+
+VP_EXPORT int vp_composite_device(vp_ctx* c, const void* d_particles_rgba, void* d_scene_rgba)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!d_particles_rgba || !d_scene_rgba) return vp_fail(c, VP_ERR_BAD_ARG, "vp_composite_device: null argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    return launch_composite(c, (const float*)d_particles_rgba, (float*)d_scene_rgba);
+}
+
+VP_EXPORT int vp_z_boundary(vp_ctx* c, const vp_camera* cam, int32_t* zb)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!cam || !zb) return vp_fail(c, VP_ERR_BAD_ARG, "vp_z_boundary: null argument");
+    if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_z_boundary before vp_set_frame");
+    *zb = hl_z_boundary(c, cam);
+    return VP_OK;
+}
+
+// ---- probes ----------------------------------------------------------------------------------------
+VP_EXPORT int vp_get_mv_positions(vp_ctx* c, float* out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!out) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_get_mv_positions before vp_set_frame");
+    memcpy(out, c->h_mvPos, c->n3 * 3 * sizeof(float));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_read_bincounts(vp_ctx* c, int32_t* counts)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!counts) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (!c->binned) return vp_fail(c, VP_ERR_STATE, "vp_read_bincounts before vp_bin");
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipStreamSynchronize(c->stream));
+    VP_HIP(hipMemcpy(counts, c->d_count, c->n3 * sizeof(int), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_read_binlist(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, int32_t* ids, int32_t cap, int32_t* n)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!n || (cap > 0 && !ids)) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (!c->binned) return vp_fail(c, VP_ERR_STATE, "vp_read_binlist before vp_bin");
+    const GridConsts& g = c->g;
+    if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipStreamSynchronize(c->stream));
+    const size_t mi = ((size_t)zz * g.Ny + yy) * g.Nx + xx;
+    int off[2];
+    VP_HIP(hipMemcpy(off, c->d_offsets + mi, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    *n = off[1] - off[0];
+    const int m = *n < cap ? *n : cap;
+    if (m > 0) VP_HIP(hipMemcpy(ids, c->d_ids + off[0], (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_read_brick(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, uint16_t* half_rgba)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!half_rgba) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_read_brick before vp_fill");
+    const GridConsts& g = c->g;
+    if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipStreamSynchronize(c->stream));
+    const size_t mi = ((size_t)zz * g.Ny + yy) * g.Nx + xx;
+    int bi = -1;
+    VP_HIP(hipMemcpy(&bi, c->d_brick_index + mi, sizeof(int), hipMemcpyDeviceToHost));
+    if (bi < 0) return vp_fail(c, VP_ERR_STATE, "metavoxel (%d,%d,%d) is empty / not owned: no brick", xx, yy, zz);
+    VP_HIP(hipMemcpy(half_rgba, c->d_bricks + (size_t)bi * nv3(c), nv3(c) * sizeof(uint2), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_read_lightmap(vp_ctx* c, float* out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!out) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_read_lightmap before vp_fill");
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipStreamSynchronize(c->stream));
+    VP_HIP(hipMemcpy(out, c->d_lightmap, lightmap_elems(c) * sizeof(float), hipMemcpyDeviceToHost));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!st) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    int rc = ensure_device(c); if (rc) return rc;
+    memset(st, 0, sizeof *st);
+    st->particles = c->P;
+    if (c->binned) {
+        st->occupied_mv = c->h_meta.occupied;
+        st->pairs = c->h_meta.pairs;
+        st->max_pairs_per_mv = c->h_meta.max_pairs;
+        st->voxels_filled = (int64_t)c->h_meta.occupied * (int64_t)nv3(c);
+    }
+    st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));
+    VP_HIP(hipStreamSynchronize(c->stream));
+    unsigned long long s = 0;
+    VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));
+    st->samples = (int64_t)s;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_last_kernel_ms(vp_ctx* c, int32_t stage, float* ms)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!ms || stage < 0 || stage > 2) return vp_fail(c, VP_ERR_BAD_ARG, "vp_last_kernel_ms: bad argument");
+    if (!c->ev_valid[stage]) return vp_fail(c, VP_ERR_STATE, "stage %d has not run", stage);
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipEventSynchronize(c->ev[stage][1]));
+    VP_HIP(hipEventElapsedTime(ms, c->ev[stage][0], c->ev[stage][1]));
+    return VP_OK;
+}

@@ -1,0 +1,271 @@
+// bin.hip -- particle binning on the GPU: the reference's BinParticlesToMetavoxels (VPR.cs:397-457) and the
+// per-particle part of FillMetavoxel's DisplacedParticle build (VPR.cs:575-588), restructured for CDNA4:
+//
+//   k_extract      caller records (AoS, arbitrary stride) -> SoA (world pos, size) + 64-byte fill record
+//   k_bin<COUNT>   one thread per particle: candidate range + exact sphere/bordered-box test, atomic count
+//   k_scan         single-workgroup exclusive scan: CSR offsets, brick slots (z-major = draw order), totals
+//   k_bin<SCATTER> same walk, atomic cursor -> unsorted CSR lists
+//   k_sort_lists   per occupied MV: rank sort -> ascending particle index (the reference's list order, :452)
+//   k_col_order    MV columns sorted by work, heaviest first (launch order of the persistent fill kernel)
+//
+// The reference clears N^3 managed lists and rebuilds a 4x4 inverse per candidate on the CPU; here the bins
+// are a CSR over an occupied-brick list and the per-MV inverse collapses to one shared 3x3 (rowsb) plus a
+// per-MV translation.  All acceptance arithmetic follows DESIGN.md section 4 exactly (bit-identical lists).
+#include "vpfx_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float rd_f32(const uint8_t* p)
+{
+    // records may be only byte-aligned from the library's point of view
+    uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    return __uint_as_float(v);
+}
+
+// sin/cos of an angle in degrees: arithmetic spec 4.2 (exact quarter-turn reduction + fmaf polynomials).
+__device__ __forceinline__ void sincos_deg(float deg, float& s, float& c)
+{
+    const float k = rintf(deg * (1.0f / 90.0f));
+    const float r = fmaf(-90.0f, k, deg);
+    const float x = r * 0.017453292519943295f;
+    const float z = x * x;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * x, x);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                          z * z, fmaf(-0.5f, z, 1.0f));
+    switch (((int)k) & 3) {
+    case 0: s = sp; c = cp; break;
+    case 1: s = cp; c = -sp; break;
+    case 2: s = -sp; c = -cp; break;
+    default: s = -cp; c = sp; break;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_extract(const uint8_t* __restrict__ raw, int P, vp_particle_layout lay, PsysConsts ps,
+          float4* __restrict__ ws4, float* __restrict__ rec)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const uint8_t* q = raw + (size_t)p * lay.stride;
+    const float lx = rd_f32(q + lay.off_position), ly = rd_f32(q + lay.off_position + 4), lz = rd_f32(q + lay.off_position + 8);
+    // wsParticlePos = particleSys.localToWorld.MultiplyPoint3x4(position)                     VPR.cs:418
+    const float wx = ((ps.L2W[0] * lx + ps.L2W[1] * ly) + ps.L2W[2] * lz) + ps.L2W[3];
+    const float wy = ((ps.L2W[4] * lx + ps.L2W[5] * ly) + ps.L2W[6] * lz) + ps.L2W[7];
+    const float wz = ((ps.L2W[8] * lx + ps.L2W[9] * ly) + ps.L2W[10] * lz) + ps.L2W[11];
+    const float size = rd_f32(q + lay.off_size);
+    float rot = rd_f32(q + lay.off_rotation);
+    if (ps.rot_in_radians) rot = rot * 57.29577951308232f;
+    const float life = rd_f32(q + lay.off_lifetime), life0 = rd_f32(q + lay.off_start_lifetime);
+    ws4[p] = make_float4(wx, wy, wz, size);
+
+    // mWorldToLocal = TRS(wsPos, AngleAxis(rotation, psys.forward), size).inverse             VPR.cs:583
+    float sh, ch;
+    sincos_deg(rot * 0.5f, sh, ch);
+    const float qx = ps.axis[0] * sh, qy = ps.axis[1] * sh, qz = ps.axis[2] * sh, qw = ch;
+    const float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    const float xx = qx * x2, yy = qy * y2, zz = qz * z2, xy = qx * y2, xz = qx * z2, yz = qy * z2;
+    const float wxx = qw * x2, wyy = qw * y2, wzz = qw * z2;
+    float R[9];
+    R[0] = 1.0f - (yy + zz); R[1] = xy - wzz;         R[2] = xz + wyy;
+    R[3] = xy + wzz;         R[4] = 1.0f - (xx + zz); R[5] = yz - wxx;
+    R[6] = xz - wyy;         R[7] = yz + wxx;         R[8] = 1.0f - (xx + yy);
+    const float inv = 1.0f / size;
+    float out[16];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float rx = R[0 * 3 + k] * inv, ry = R[1 * 3 + k] * inv, rz = R[2 * 3 + k] * inv;
+        out[k * 4 + 0] = rx; out[k * 4 + 1] = ry; out[k * 4 + 2] = rz;
+        out[k * 4 + 3] = -((rx * wx + ry * wy) + rz * wz);
+    }
+    out[12] = life / life0;            // mOpacity = lifetime / startLifetime                  VPR.cs:586
+    out[13] = size * 0.5f;             // mRadius                                              VPR.cs:585
+    out[14] = 0.f; out[15] = 0.f;
+    float4* dst = reinterpret_cast<float4*>(rec + 16 * (size_t)p);
+    dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+    dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+    dst[3] = make_float4(out[12], out[13], out[14], out[15]);
+}
+
+// One thread per particle.  MODE 0: count, MODE 1: scatter.                          VPR.cs:415-456
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restrict__ mvPos,
+      int* __restrict__ count_or_cursor, const int* __restrict__ offsets, int* __restrict__ ids)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float4 w = ws4[p];
+    // lsParticlePos = light.worldToLocal * ws                                                  :419
+    const float lx = ((g.Linv[0] * w.x + g.Linv[1] * w.y) + g.Linv[2] * w.z) + g.Linv[3];
+    const float ly = ((g.Linv[4] * w.x + g.Linv[5] * w.y) + g.Linv[6] * w.z) + g.Linv[7];
+    const float lz = ((g.Linv[8] * w.x + g.Linv[9] * w.y) + g.Linv[10] * w.z) + g.Linv[11];
+    // pIndex = (ls - lsGridCenter)/s + N*0.5                                                   :422-423
+    const float pix = (lx - g.lsO[0]) / g.s + (float)g.Nx * 0.5f;
+    const float piy = (ly - g.lsO[1]) / g.s + (float)g.Ny * 0.5f;
+    const float piz = (lz - g.lsO[2]) / g.s + (float)g.Nz * 0.5f;
+    const float fe = (float)(int)rintf((w.w / 2.0f) / g.s);      // pExtents = RoundToInt(r/s)  :425
+    // Vector3.Max(zero, ..) / Vector3.Min(limit, ..) then C# (int) truncation                  :431-438
+    const int x0 = (int)fmaxf(0.f, pix - fe), x1 = (int)fminf((float)(g.Nx - 1), pix + fe);
+    const int y0 = (int)fmaxf(0.f, piy - fe), y1 = (int)fminf((float)(g.Ny - 1), piy + fe);
+    int z0 = (int)fmaxf(0.f, piz - fe), z1 = (int)fminf((float)(g.Nz - 1), piz + fe);
+    // only the owned slab is binned (other slabs belong to other GPUs)
+    z0 = max(z0, g.z0); z1 = min(z1, g.z1 - 1);
+    const float r = (w.w / 2.0f) / g.sb;                         // mvParticleRadius           :445
+    for (int zz = z0; zz <= z1; ++zz)
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                const int mi = (zz * g.Ny + yy) * g.Nx + xx;
+                const float mx = mvPos[3 * mi], my = mvPos[3 * mi + 1], mz = mvPos[3 * mi + 2];
+                float r2 = r * r;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float a = g.rowsb[k * 3], bq = g.rowsb[k * 3 + 1], cq = g.rowsb[k * 3 + 2];
+                    const float t = -((a * mx + bq * my) + cq * mz);
+                    const float m = ((a * w.x + bq * w.y) + cq * w.z) + t;
+                    // MathUtil.DoesBoxIntersectSphere                                     MathUtil.cs:15-22
+                    if (m < -0.5f) { const float d = m - (-0.5f); r2 -= d * d; }
+                    else if (m > 0.5f) { const float d = m - 0.5f; r2 -= d * d; }
+                }
+                if (r2 > 0.f) {
+                    if (MODE == 0) atomicAdd(&count_or_cursor[mi], 1);
+                    else { const int slot = atomicAdd(&count_or_cursor[mi], 1); ids[offsets[mi] + slot] = p; }
+                }
+            }
+}
+
+// Exclusive scan of count[] -> offsets[], brick slots for occupied slab MVs in linear (= z-major draw) order.
+__global__ void __launch_bounds__(1024)
+k_scan(const int* __restrict__ count, int n3, int nxy, int z0, int z1, int* __restrict__ offsets,
+       int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor, DevMeta* __restrict__ meta)
+{
+    __shared__ int s_pairs[1024], s_occ[1024], s_max[1024];
+    const int t = threadIdx.x;
+    const int per = (n3 + 1023) / 1024;
+    const int lo = min(t * per, n3), hi = min(lo + per, n3);
+    int sp = 0, so = 0, mx = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int cnt = count[i];
+        const int zz = i / nxy;
+        sp += cnt; so += (cnt != 0 && zz >= z0 && zz < z1) ? 1 : 0; mx = max(mx, cnt);
+    }
+    s_pairs[t] = sp; s_occ[t] = so; s_max[t] = mx;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
+        int a = 0, b = 0, m = 0;
+        if (t >= d) { a = s_pairs[t - d]; b = s_occ[t - d]; m = s_max[t - d]; }
+        __syncthreads();
+        if (t >= d) { s_pairs[t] += a; s_occ[t] += b; s_max[t] = max(s_max[t], m); }
+        __syncthreads();
+    }
+    int bp = s_pairs[t] - sp, bo = s_occ[t] - so;
+    for (int i = lo; i < hi; ++i) {
+        const int cnt = count[i];
+        const int zz = i / nxy;
+        offsets[i] = bp; cursor[i] = 0;
+        const bool occ = (cnt != 0 && zz >= z0 && zz < z1);                  // VPR.cs:511
+        brick_index[i] = occ ? bo : -1;
+        if (occ) occ_list[bo] = i;
+        bp += cnt; bo += occ ? 1 : 0;
+    }
+    if (t == 1023) {
+        offsets[n3] = s_pairs[1023];
+        meta->occupied = s_occ[1023]; meta->pairs = s_pairs[1023]; meta->max_pairs = s_max[1023];
+        meta->unsorted_lists = 0;
+    }
+}
+
+// Rank sort of one MV's list (ids are unique within a list).  One workgroup per occupied MV.
+#define SORT_CAP 4096
+__global__ void __launch_bounds__(256)
+k_sort_lists(const int* __restrict__ occ_list, const int* __restrict__ offsets, const int* __restrict__ in,
+             int* __restrict__ out, DevMeta* __restrict__ meta)
+{
+    __shared__ int s_ids[SORT_CAP];
+    const int mi = occ_list[blockIdx.x];
+    const int off = offsets[mi], n = offsets[mi + 1] - off;
+    if (n > SORT_CAP) {      // pathological list: keep arrival order (only the fp32 density sum order changes)
+        for (int i = threadIdx.x; i < n; i += 256) out[off + i] = in[off + i];
+        if (threadIdx.x == 0) atomicAdd(&meta->unsorted_lists, 1);
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += 256) s_ids[i] = in[off + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int v = s_ids[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (s_ids[j] < v) ? 1 : 0;
+        out[off + rank] = v;
+    }
+}
+
+// MV columns ordered by pair count, heaviest first (longest-processing-time-first dispatch of the fill).
+#define COL_CAP 16384
+__global__ void __launch_bounds__(1024)
+k_col_order(const int* __restrict__ count, int nxy, int z0, int z1, int* __restrict__ colorder)
+{
+    __shared__ int s_work[COL_CAP];
+    if (nxy > COL_CAP) { for (int i = threadIdx.x; i < nxy; i += 1024) colorder[i] = i; return; }
+    for (int i = threadIdx.x; i < nxy; i += 1024) {
+        int wsum = 0;
+        for (int zz = z0; zz < z1; ++zz) { const int cnt = count[zz * nxy + i]; wsum += cnt ? cnt + 8 : 0; }
+        s_work[i] = wsum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nxy; i += 1024) {
+        const int w = s_work[i];
+        int rank = 0;
+        for (int j = 0; j < nxy; ++j) { const int wj = s_work[j]; rank += (wj > w || (wj == w && j < i)) ? 1 : 0; }
+        colorder[rank] = i;
+    }
+}
+
+}  // namespace
+
+int launch_extract(vp_ctx* c)
+{
+    if (c->P == 0) return VP_OK;
+    hipLaunchKernelGGL(k_extract, dim3((c->P + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_raw, c->P, c->lay, c->psys, c->d_ws, c->d_rec);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int launch_bin(vp_ctx* c)
+{
+    const GridConsts& g = c->g;
+    const int n3 = (int)c->n3, nxy = g.Nx * g.Ny;
+    const int nb = (c->P + 255) / 256;
+    VP_HIP(hipMemsetAsync(c->d_count, 0, c->n3 * sizeof(int), c->stream));
+    VP_HIP(hipEventRecord(c->ev[0][0], c->stream));
+    if (c->P > 0) {
+        hipLaunchKernelGGL(k_bin<0>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_count,
+                           (const int*)nullptr, (int*)nullptr);
+    }
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1, c->d_offsets,
+                       c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
+    hipLaunchKernelGGL(k_col_order, dim3(1), dim3(1024), 0, c->stream, c->d_count, nxy, g.z0, g.z1, c->d_colorder);
+    VP_HIP(hipGetLastError());
+    // totals are needed on the host to size the pair and brick pools
+    VP_HIP(hipMemcpyAsync(&c->h_meta, c->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, c->stream));
+    VP_HIP(hipStreamSynchronize(c->stream));
+    const size_t pairs = (size_t)c->h_meta.pairs;
+    if (pairs > c->pairs_cap) {
+        if (c->d_ids) VP_HIP(hipFree(c->d_ids));
+        if (c->d_ids_tmp) VP_HIP(hipFree(c->d_ids_tmp));
+        c->d_ids = c->d_ids_tmp = nullptr;
+        c->pairs_cap = pairs + pairs / 4 + 1024;
+        VP_HIP(hipMalloc(&c->d_ids, c->pairs_cap * sizeof(int)));
+        VP_HIP(hipMalloc(&c->d_ids_tmp, c->pairs_cap * sizeof(int)));
+    }
+    if (c->P > 0 && pairs > 0) {
+        hipLaunchKernelGGL(k_bin<1>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_cursor,
+                           (const int*)c->d_offsets, c->d_ids_tmp);
+        hipLaunchKernelGGL(k_sort_lists, dim3(c->h_meta.occupied), dim3(256), 0, c->stream, c->d_occ_list, c->d_offsets,
+                           (const int*)c->d_ids_tmp, c->d_ids, c->d_meta);
+        VP_HIP(hipGetLastError());
+    }
+    VP_HIP(hipEventRecord(c->ev[0][1], c->stream));
+    c->ev_valid[0] = true;
+    return VP_OK;
+}

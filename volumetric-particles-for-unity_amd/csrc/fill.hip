@@ -1,0 +1,342 @@
+// fill.hip -- the FillVolume pass (Fill.shader:152-274 driven by VPR.cs:495-609) as ONE persistent launch.
+//
+// Reference shape: one Graphics.Blit per occupied metavoxel (~11k draws at the 32^3 x 32^3 config), each
+// fragment owning one voxel column: nv slices x P_mv full 4x4 mat-vec coverage tests, then a serial
+// front-to-back propagate + RGBA16F store; draws serialised in z through a UAV (lightPropogationTex).
+//
+// CDNA4 shape (this file):
+//   * workgroup = 16x16 voxel columns (4 waves, each 16 px wide x 4 py: every slice store of a wave is four
+//     full 128-byte lines of the brick), persistent along the light axis: it walks its MV column zz = z0..z1
+//     carrying the transmitted light in a register, so the z-order dependency never leaves the chip and the
+//     light map is written once;
+//   * workgroups are dispatched heaviest-column-first (k_col_order) to bound the tail;
+//   * per (wave, particle): the column is a line ps(s) = A + s*B in particle space, so coverage is a quadratic
+//     in the slice index; each lane solves it, a DPP OR-reduction merges the per-lane slice masks, and only the
+//     wave-uniform slice range is tested (exact test unchanged: |ps|^2 <= 0.25, Fill.shader:172);
+//   * particle records are wave-uniform -> scalar loads (s_load_dwordx16), matrix elements live in SGPRs;
+//   * per-slice accumulators (density sum, ao max) are register arrays indexed by the uniform slice
+//     (s_set_gpr_idx), no LDS, no scratch;
+//   * the displacement cubemap is pre-expanded to bilinear footprints: one 16-byte load per covered voxel
+//     instead of four texel fetches (gfx950 has no image/sampler hardware).
+// Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernel is ALU-limited well before it.
+#include "vpfx_internal.h"
+
+namespace {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_half2(float a, float b)
+{
+    half2_t h = {(_Float16)a, (_Float16)b};      // v_cvt_f16_f32: round-to-nearest-even
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// OR-reduction across the 64 lanes of a wave with DPP row shifts/broadcasts; result is wave-uniform.
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float fdiv(float a, float b)
+{
+    return EXACT ? a / b : a * __builtin_amdgcn_rcpf(b);
+}
+
+// kernel pointer arguments are passed one by one as __restrict__ so that wave-uniform reads (particle records,
+// CSR offsets, MV positions) are provably unclobbered by the brick stores and become scalar (SMEM) loads.
+#define FILL_PTR_PARAMS                                                                                      \
+    const float* __restrict__ p_mvPos, const int* __restrict__ p_offsets, const int* __restrict__ p_ids,     \
+    const float* __restrict__ p_rec, const int* __restrict__ p_brick_index, const int* __restrict__ p_colorder, \
+    const float4* __restrict__ p_cubequads, const float* __restrict__ p_depthmap /* nullable */,             \
+    const float* __restrict__ p_light_in /* nullable => 1.0 */, float* __restrict__ p_light_out,             \
+    uint2* __restrict__ p_bricks, float2* __restrict__ p_dens_ao /* split-fill scratch */
+#define FILL_PTR_ARGS(P) (P).mvPos, (P).offsets, (P).ids, (P).rec, (P).brick_index, (P).colorder, (P).cubequads, \
+                         (P).depthmap, (P).light_in, (P).light_out, (P).bricks, (P).dens_ao
+
+struct FillPtrs {
+    const float* mvPos; const int* offsets; const int* ids; const float* rec; const int* brick_index;
+    const int* colorder; const float4* cubequads; const float* depthmap; const float* light_in;
+    float* light_out; uint2* bricks; float2* dens_ao;
+};
+
+// compute_voxel_color (Fill.shader:110-135) for a covered voxel; ps = voxel in particle space, d2 = |ps|^2.
+template <bool EXACT>
+__device__ __forceinline__ void voxel_color(const FillConsts& f, const float4* __restrict__ quads, float psx, float psy, float psz,
+                                            float d2, float opacity, float& den, float& net)
+{
+    // texCUBE(_DisplacementTexture, 2*ps).x -- D3D face selection, per-face bilinear, clamp
+    const float ax = fabsf(psx), ay = fabsf(psy), az = fabsf(psz);
+    int face; float ma, sc, tc;
+    if (ax >= ay && ax >= az) { ma = ax; if (psx >= 0.f) { face = 0; sc = -psz; tc = -psy; } else { face = 1; sc = psz; tc = -psy; } }
+    else if (ay >= az)        { ma = ay; if (psy >= 0.f) { face = 2; sc = psx; tc = psz; } else { face = 3; sc = psx; tc = -psz; } }
+    else                      { ma = az; if (psz >= 0.f) { face = 4; sc = psx; tc = -psy; } else { face = 5; sc = -psx; tc = -psy; } }
+    float u = 0.f, v = 0.f;
+    if (ma > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma); u = sc * inv; v = tc * inv; }
+    const float fx = fmaf(u, f.half_s, f.half_s_m05), fy = fmaf(v, f.half_s, f.half_s_m05);
+    const float x0 = floorf(fx), y0 = floorf(fy);
+    const float tx = fx - x0, ty = fy - y0;
+    const int S = f.cubeS;
+    const int ix = min(max((int)x0, -1), S - 1), iy = min(max((int)y0, -1), S - 1);
+    const float4 q = quads[(face * (S + 1) + (iy + 1)) * (S + 1) + (ix + 1)];     // (t00, t10, t01, t11)
+    const float a = fmaf(tx, q.y - q.x, q.x), b = fmaf(tx, q.w - q.z, q.z);
+    const float raw = fmaf(ty, b - a, a);
+    net = fmaf(f.D, raw, f.one_minus_D);                                          // netDisplacement   :119
+    const float d2q = 4.0f * d2;                                                  // dot(2ps, 2ps)     :121
+    float t = fdiv<EXACT>(d2q - net, 0.7f * net - net);                           // smoothstep        :126
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    const float base = (t * t) * (3.0f - 2.0f * t);
+    den = base * f.opacity_factor;                                                // :127
+    if (f.fade == 1) den *= opacity;                                              // :130-131
+}
+
+// MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
+// (propagation with T_in = 1) to light_out.
+template <int NV, bool EXACT, int MODE>
+__global__ void __launch_bounds__(256)
+k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
+{
+    constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
+    constexpr int TW = NV / 16;                      // 16x16-column tiles per MV edge
+    constexpr int TPM = TW * TW;
+    const int col = p_colorder[blockIdx.x / TPM];
+    const int tile = blockIdx.x % TPM;
+    const int xx = col % g.Nx, yy = col / g.Nx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = (tile % TW) * 16 + (lane & 15);
+    const int py = (tile / TW) * 16 + wave * 4 + (lane >> 4);
+    const int LW = g.Nx * NV;
+    const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
+
+    // get_voxel_world_pos: normPos = ((svPos - nv/2)/nv, (slice - nv/2)/nv)             Fill.shader:96-107
+    const float fnv = (float)NV;
+    const float nx = (((float)px + 0.5f) - fnv / 2.0f) / fnv;
+    const float ny = (((float)py + 0.5f) - fnv / 2.0f) / fnv;
+    const float nz = (0.0f - fnv / 2.0f) / fnv;
+    const float dm = p_depthmap ? p_depthmap[lmi] : 1.0f;                                // tex2D(_LightDepthMap) :217
+    const float lsSceneDepth = (dm - f.bq) * f.inv_a;                                    // :218-219
+
+    float prop = (MODE == 0 && p_light_in) ? p_light_in[lmi] : 1.0f;                     // GL.Clear(Color.red) VPR.cs:499
+
+    for (int zz = g.z0; zz < g.z1; ++zz) {                                               // z-major = draw order VPR.cs:505
+        const int mi = (zz * g.Ny + yy) * g.Nx + xx;
+        const int bi = p_brick_index[mi];
+        if (bi < 0) continue;                                                            // empty MV skipped    VPR.cs:511
+        const int off = p_offsets[mi];
+        const int n = p_offsets[mi + 1] - off;
+        const float mvx = p_mvPos[3 * mi], mvy = p_mvPos[3 * mi + 1], mvz = p_mvPos[3 * mi + 2];
+        // _MetavoxelToWorld = TRS(mvPos, lightRot, sb)                                                  VPR.cs:596
+        const float v0x = ((g.Rsb[0] * nx + g.Rsb[1] * ny) + g.Rsb[2] * nz) + mvx;
+        const float v0y = ((g.Rsb[3] * nx + g.Rsb[4] * ny) + g.Rsb[5] * nz) + mvy;
+        const float v0z = ((g.Rsb[6] * nx + g.Rsb[7] * ny) + g.Rsb[8] * nz) + mvz;
+        // shadow index                                                                           Fill.shader:211-222
+        const float ddx = v0x - f.camp[0], ddy = v0y - f.camp[1], ddz = v0z - f.camp[2];
+        const float lz0 = (g.Rl[2] * ddx + g.Rl[5] * ddy) + g.Rl[8] * ddz;
+        const float q = (lsSceneDepth - lz0) / g.one;
+        const int shadowIndex = !(q < 2.0e9f) ? 2000000000 : (q < -2.0e9f ? -2000000000 : (int)q);
+
+        float T = (zz == 0) ? f.init_light : prop;                                       // :224
+        prop = T;
+        uint2* brick = p_bricks + (size_t)bi * NV * NV * NV;
+        float2* scratch = p_dens_ao + (size_t)bi * NV * NV * NV;
+
+#pragma unroll 1
+        for (int c0 = 0; c0 < NV; c0 += CH) {
+            float dens[CH], ao[CH];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) { dens[s] = 0.f; ao[s] = 0.f; }                 // "clear it"  :178-181
+
+#pragma unroll 1
+            for (int i = 0; i < n; ++i) {
+                const int pid = __builtin_amdgcn_readfirstlane(p_ids[off + i]);
+                const float* r = p_rec + 16 * (size_t)pid;
+                const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
+                const float r8 = r[8], r9 = r[9], r10 = r[10], r11 = r[11], opacity = r[12];
+                // ps(s) = A + s*B (arithmetic spec 4.4): A = W2P*(v0,1), B = W2P_linear * dstep
+                const float Ax = fmaf(r2, v0z, fmaf(r1, v0y, fmaf(r0, v0x, r3)));
+                const float Ay = fmaf(r6, v0z, fmaf(r5, v0y, fmaf(r4, v0x, r7)));
+                const float Az = fmaf(r10, v0z, fmaf(r9, v0y, fmaf(r8, v0x, r11)));
+                const float Bx = fmaf(r2, f.dstep[2], fmaf(r1, f.dstep[1], r0 * f.dstep[0]));
+                const float By = fmaf(r6, f.dstep[2], fmaf(r5, f.dstep[1], r4 * f.dstep[0]));
+                const float Bz = fmaf(r10, f.dstep[2], fmaf(r9, f.dstep[1], r8 * f.dstep[0]));
+                // conservative slice interval of this lane's column (culling only; the exact test follows)
+                const float qa = fmaf(Bz, Bz, fmaf(By, By, Bx * Bx));
+                const float qh = fmaf(Az, Bz, fmaf(Ay, By, Ax * Bx));
+                const float qc = fmaf(Az, Az, fmaf(Ay, Ay, Ax * Ax)) - 0.25f;
+                const float disc = fmaf(qh, qh, -qa * qc) + 2.0e-3f * qa;
+                const float inv_a = __builtin_amdgcn_rcpf(qa);
+                const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * inv_a;
+                const float sc = -qh * inv_a;
+                int lo = (int)ceilf(sc - sq), hi = (int)floorf(sc + sq);
+                lo = max(lo, c0); hi = min(hi, c0 + CH - 1);
+                uint32_t m = 0;
+                if (disc >= 0.f && lo <= hi) {
+                    const int w = hi - lo + 1;
+                    m = (w >= 32 ? 0xffffffffu : ((1u << w) - 1u)) << (lo - c0);
+                }
+                const uint32_t wm = wave_or(m);
+                if (wm == 0) continue;
+                const int s_first = __builtin_ctz(wm), s_last = 31 - __builtin_clz(wm);
+#pragma unroll 1
+                for (int s = s_first; s <= s_last; ++s) {
+                    const float fs = (float)(c0 + s);
+                    const float psx = fmaf(fs, Bx, Ax), psy = fmaf(fs, By, Ay), psz = fmaf(fs, Bz, Az);
+                    const float d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
+                    const bool hit = d2 <= 0.25f;                                        // Fill.shader:172,196
+                    if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                    if (hit) {
+                        float den, net;
+                        voxel_color<EXACT>(f, p_cubequads, psx, psy, psz, d2, opacity, den, net);
+                        dens[s] += den;                                                  // :200
+                        ao[s] = fmaxf(ao[s], net);                                       // :201
+                    }
+                }
+            }
+
+            // propagate + store this chunk                                               Fill.shader:231-269
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const int sg = c0 + s;
+                const bool inShadow = sg >= shadowIndex;
+                if (inShadow) T = 0.0f;
+                else if (sg < f.border_index) prop = T;
+                const size_t vi = ((size_t)sg * NV + py) * NV + px;
+                if (MODE == 0) {
+                    const float cr = 0.4f * T + f.amb[0] * ao[s];
+                    const float cg = 0.4f * T + f.amb[1] * ao[s];
+                    const float cb = 0.4f * T + f.amb[2] * ao[s];
+                    brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, dens[s]));  // volumeTex[int3(xy, slice)]
+                } else {
+                    scratch[vi] = make_float2(dens[s], ao[s]);
+                }
+                T *= 1.0f / (1.0f + dens[s]);                                            // rcp(1 + density) :244
+            }
+        }
+    }
+    p_light_out[lmi] = prop;                                                             // lightPropogationTex[..] :250
+}
+
+// Second half of the split (multi-GPU) fill: stream density/ao back, propagate with the true incoming light.
+template <int NV>
+__global__ void __launch_bounds__(256)
+k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
+{
+    constexpr int TW = NV / 16;
+    constexpr int TPM = TW * TW;
+    const int col = p_colorder[blockIdx.x / TPM];
+    const int tile = blockIdx.x % TPM;
+    const int xx = col % g.Nx, yy = col / g.Nx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = (tile % TW) * 16 + (lane & 15);
+    const int py = (tile / TW) * 16 + wave * 4 + (lane >> 4);
+    const int LW = g.Nx * NV;
+    const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
+    const float fnv = (float)NV;
+    const float nx = (((float)px + 0.5f) - fnv / 2.0f) / fnv;
+    const float ny = (((float)py + 0.5f) - fnv / 2.0f) / fnv;
+    const float nz = (0.0f - fnv / 2.0f) / fnv;
+    const float dm = p_depthmap ? p_depthmap[lmi] : 1.0f;
+    const float lsSceneDepth = (dm - f.bq) * f.inv_a;
+    float prop = p_light_in ? p_light_in[lmi] : 1.0f;
+    for (int zz = g.z0; zz < g.z1; ++zz) {
+        const int mi = (zz * g.Ny + yy) * g.Nx + xx;
+        const int bi = p_brick_index[mi];
+        if (bi < 0) continue;
+        const float mvx = p_mvPos[3 * mi], mvy = p_mvPos[3 * mi + 1], mvz = p_mvPos[3 * mi + 2];
+        const float v0x = ((g.Rsb[0] * nx + g.Rsb[1] * ny) + g.Rsb[2] * nz) + mvx;
+        const float v0y = ((g.Rsb[3] * nx + g.Rsb[4] * ny) + g.Rsb[5] * nz) + mvy;
+        const float v0z = ((g.Rsb[6] * nx + g.Rsb[7] * ny) + g.Rsb[8] * nz) + mvz;
+        const float ddx = v0x - f.camp[0], ddy = v0y - f.camp[1], ddz = v0z - f.camp[2];
+        const float lz0 = (g.Rl[2] * ddx + g.Rl[5] * ddy) + g.Rl[8] * ddz;
+        const float q = (lsSceneDepth - lz0) / g.one;
+        const int shadowIndex = !(q < 2.0e9f) ? 2000000000 : (q < -2.0e9f ? -2000000000 : (int)q);
+        float T = (zz == 0) ? f.init_light : prop;
+        prop = T;
+        uint2* brick = p_bricks + (size_t)bi * NV * NV * NV;
+        const float2* scratch = p_dens_ao + (size_t)bi * NV * NV * NV;
+#pragma unroll 8
+        for (int sg = 0; sg < NV; ++sg) {
+            const size_t vi = ((size_t)sg * NV + py) * NV + px;
+            const float2 da = scratch[vi];
+            const bool inShadow = sg >= shadowIndex;
+            if (inShadow) T = 0.0f;
+            else if (sg < f.border_index) prop = T;
+            const float cr = 0.4f * T + f.amb[0] * da.y;
+            const float cg = 0.4f * T + f.amb[1] * da.y;
+            const float cb = 0.4f * T + f.amb[2] * da.y;
+            brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, da.x));
+            T *= 1.0f / (1.0f + da.x);
+        }
+    }
+    p_light_out[lmi] = prop;
+}
+
+// Expand the cubemap into bilinear footprints: quad(face, iy, ix) = texels (ix,iy),(ix+1,iy),(ix,iy+1),(ix+1,iy+1)
+// with clamp addressing, for ix, iy in [-1, S-1].
+__global__ void __launch_bounds__(256)
+k_build_cubequads(const float* __restrict__ cube, int S, float4* __restrict__ quads)
+{
+    const int n = 6 * (S + 1) * (S + 1);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ix = i % (S + 1) - 1, iy = (i / (S + 1)) % (S + 1) - 1, face = i / ((S + 1) * (S + 1));
+    const int x0 = min(max(ix, 0), S - 1), x1 = min(max(ix + 1, 0), S - 1);
+    const int y0 = min(max(iy, 0), S - 1), y1 = min(max(iy + 1, 0), S - 1);
+    const float* fc = cube + (size_t)face * S * S;
+    quads[i] = make_float4(fc[y0 * S + x0], fc[y0 * S + x1], fc[y1 * S + x0], fc[y1 * S + x1]);
+}
+
+template <int NV>
+int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
+{
+    constexpr int TPM = (NV / 16) * (NV / 16);
+    const dim3 grid(c->g.Nx * c->g.Ny * TPM), block(256);
+    if (mode == 0) {
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+    } else if (mode == 1) {
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        else       hipLaunchKernelGGL((k_fill<NV, false, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+    } else {
+        hipLaunchKernelGGL((k_fill_finish<NV>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+    }
+    return VP_OK;
+}
+
+}  // namespace
+
+int launch_build_cubequads(vp_ctx* c, const float* d_cube, int S)
+{
+    const int n = 6 * (S + 1) * (S + 1);
+    hipLaunchKernelGGL(k_build_cubequads, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cube, S, c->d_cubequads);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out)
+{
+    FillPtrs P{};
+    P.mvPos = c->d_mvPos; P.offsets = c->d_offsets; P.ids = c->d_ids; P.rec = c->d_rec;
+    P.brick_index = c->d_brick_index; P.colorder = c->d_colorder; P.cubequads = c->d_cubequads;
+    P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
+    P.light_in = d_light_in; P.light_out = d_light_out;
+    P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao;
+    const bool exact = c->cfg.reserved[0] == 1;      // cfg.reserved[0] = 1: IEEE divisions everywhere (parity builds)
+    VP_HIP(hipEventRecord(c->ev[1][0], c->stream));
+    switch (c->g.nv) {
+    case 16: launch_fill_nv<16>(c, mode, P, exact); break;
+    case 32: launch_fill_nv<32>(c, mode, P, exact); break;
+    case 64: launch_fill_nv<64>(c, mode, P, exact); break;
+    default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", c->g.nv);
+    }
+    VP_HIP(hipGetLastError());
+    VP_HIP(hipEventRecord(c->ev[1][1], c->stream));
+    c->ev_valid[1] = true;
+    return VP_OK;
+}

@@ -1,0 +1,201 @@
+// host_logic.cpp -- the C#-side ("L2") logic of the reference's hot path, restated as host C++:
+// grid layout, per-pass uniforms, metavoxel ordering.  Counterpart of
+//   VolumetricParticleRenderer.UpdateMetavoxelPositions      VPR.cs:370-394
+//   SetFillPassConstants / SetRaymarchPassConstants          VPR.cs:523-554, 716-763
+//   SortMetavoxelSlicesFarToNearFromEye + zBoundary          VPR.cs:613-648
+// fp32 with the operation order of the arithmetic spec; no contraction.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "vpfx_internal.h"
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+inline float cm(const float* m, int r, int c) { return m[c * 4 + r]; }   // Unity Matrix4x4 is column-major
+
+// Matrix4x4.MultiplyPoint3x4 on a row-packed 3x4
+inline V3 mul_point_rows(const float* rows, V3 v)
+{
+    V3 r;
+    r.x = ((rows[0] * v.x + rows[1] * v.y) + rows[2] * v.z) + rows[3];
+    r.y = ((rows[4] * v.x + rows[5] * v.y) + rows[6] * v.z) + rows[7];
+    r.z = ((rows[8] * v.x + rows[9] * v.y) + rows[10] * v.z) + rows[11];
+    return r;
+}
+
+}  // namespace
+
+void hl_build_grid(vp_ctx* c)
+{
+    GridConsts& g = c->g;
+    const vp_config& cfg = c->cfg;
+    g.Nx = cfg.num_mv[0]; g.Ny = cfg.num_mv[1]; g.Nz = cfg.num_mv[2];
+    g.nv = cfg.num_voxels; g.b = cfg.num_border;
+    g.z0 = cfg.slab_z0; g.z1 = cfg.slab_z1;
+    if (g.z0 == 0 && g.z1 == 0) g.z1 = g.Nz;
+    g.s = cfg.mv_scale;
+    g.sb = g.s * (float)g.nv / (float)(g.nv - 2 * g.b);        // mvScaleWithBorder              VPR.cs:139
+    g.one = g.sb / (float)g.nv;                                 // oneVoxelSize                   Fill.shader:160
+    g.inv_sb = 1.0f / g.sb;
+
+    const float* L = c->L;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) g.Rl[r * 3 + k] = cm(L, r, k);
+    // worldToLocal of the rigid light transform: rows = Rl^T, translation = -(row . t)
+    const V3 t{cm(L, 0, 3), cm(L, 1, 3), cm(L, 2, 3)};
+    for (int k = 0; k < 3; ++k) {
+        float rx = g.Rl[0 * 3 + k] * 1.0f, ry = g.Rl[1 * 3 + k] * 1.0f, rz = g.Rl[2 * 3 + k] * 1.0f;
+        g.Linv[k * 4 + 0] = rx; g.Linv[k * 4 + 1] = ry; g.Linv[k * 4 + 2] = rz;
+        g.Linv[k * 4 + 3] = -((rx * t.x + ry * t.y) + rz * t.z);
+    }
+    for (int i = 0; i < 3; ++i) g.gc[i] = c->gc[i];
+    const V3 lsO = mul_point_rows(g.Linv, V3{c->gc[0], c->gc[1], c->gc[2]});     // lsWorldOrigin    VPR.cs:380
+    g.lsO[0] = lsO.x; g.lsO[1] = lsO.y; g.lsO[2] = lsO.z;
+    for (int i = 0; i < 9; ++i) g.Rsb[i] = g.Rl[i] * g.sb;
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 3; ++j) g.rowsb[k * 3 + j] = g.Rl[j * 3 + k] * g.inv_sb;
+    // forward.normalized
+    const V3 f{g.Rl[2], g.Rl[5], g.Rl[8]};
+    const float mag = std::sqrt((f.x * f.x + f.y * f.y) + f.z * f.z);
+    if (mag > 1e-5f) { g.fwd[0] = f.x / mag; g.fwd[1] = f.y / mag; g.fwd[2] = f.z / mag; }
+    else g.fwd[0] = g.fwd[1] = g.fwd[2] = 0.f;
+
+    // light localToWorld as rows
+    float Lrows[12];
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) Lrows[r * 4 + k] = cm(L, r, k);
+    for (int zz = 0; zz < g.Nz; ++zz)
+        for (int yy = 0; yy < g.Ny; ++yy)
+            for (int xx = 0; xx < g.Nx; ++xx) {
+                // integer N/2 (VPR.cs:388): zz = 0 is the slice nearest the light
+                const V3 off{(float)(g.Nx / 2 - xx) * g.s, (float)(g.Ny / 2 - yy) * g.s, (float)(g.Nz / 2 - zz) * g.s};
+                const V3 p = mul_point_rows(Lrows, V3{lsO.x - off.x, lsO.y - off.y, lsO.z - off.z});
+                float* d = c->h_mvPos + 3 * (((size_t)zz * g.Ny + yy) * g.Nx + xx);
+                d[0] = p.x; d[1] = p.y; d[2] = p.z;
+            }
+}
+
+void hl_build_psys(vp_ctx* c, const float m[16])
+{
+    PsysConsts& p = c->psys;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) p.L2W[r * 4 + k] = cm(m, r, k);
+    // particleSys.transform.forward; Quaternion.AngleAxis normalises its axis      VPR.cs:583
+    const V3 a{cm(m, 0, 2), cm(m, 1, 2), cm(m, 2, 2)};
+    const float am = std::sqrt((a.x * a.x + a.y * a.y) + a.z * a.z);
+    if (am > 0.f) { p.axis[0] = a.x / am; p.axis[1] = a.y / am; p.axis[2] = a.z / am; }
+    else { p.axis[0] = 0.f; p.axis[1] = 0.f; p.axis[2] = 1.f; }
+    p.rot_in_radians = c->lay.rotation_in_radians;
+}
+
+void hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p)
+{
+    FillConsts& f = c->fc;
+    const GridConsts& g = c->g;
+    f.opacity_factor = p->opacity_factor;
+    f.D = p->displacement_scale;
+    f.one_minus_D = 1.0f - p->displacement_scale;
+    f.init_light = p->init_light_intensity;
+    for (int i = 0; i < 3; ++i) f.amb[i] = p->ambient[i];
+    f.fade = p->fade_out_particles;
+    const float a = 1.0f / (p->light_far - p->light_near);       // Fill.shader:218
+    f.bq = -p->light_near * a;
+    f.inv_a = 1.0f / a;
+    for (int i = 0; i < 3; ++i) {
+        f.camp[i] = g.gc[i] - g.fwd[i] * p->light_cam_distance;  // UpdatePositionOfCameraAtLight  VPR.cs:365
+        f.dstep[i] = g.fwd[i] * g.one;
+    }
+    f.cubeS = c->cubeS;
+    f.half_s = 0.5f * (float)c->cubeS;
+    f.half_s_m05 = f.half_s - 0.5f;
+    const int bclamp = std::min(std::max(g.b, 0), g.nv - 2);     // Mathf.Clamp(b, 0, nv-2)        VPR.cs:528
+    f.border_index = g.nv - bclamp;
+}
+
+int hl_z_boundary(const vp_ctx* c, const vp_camera* cam)
+{
+    const GridConsts& g = c->g;
+    const V3 lsCam = mul_point_rows(g.Linv, V3{cam->cam_pos[0], cam->cam_pos[1], cam->cam_pos[2]});
+    const float* p0 = c->h_mvPos;   // mvGrid[0,0,0].mPos
+    const float lsFirst = mul_point_rows(g.Linv, V3{p0[0], p0[1], p0[2]}).z;
+    const float over = (lsCam.z - lsFirst) / g.s;                // mvBlendOverIndex               VPR.cs:644
+    int zb = (int)std::rint(over);                               // Mathf.RoundToInt: half-to-even
+    return std::min(std::max(zb, -1), g.Nz - 1);
+}
+
+// rank[yy*Nx+xx] = position of (xx,yy) in the ASCENDING distance list (stable on ties, list built yy-major).
+// Phase A (OVER) walks ranks descending, phase B (UNDER) ascending.                  VPR.cs:613-632
+void hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank)
+{
+    const GridConsts& g = c->g;
+    const int nxy = g.Nx * g.Ny;
+    std::vector<float> key(nxy);
+    for (int i = 0; i < nxy; ++i) {
+        const float* p = c->h_mvPos + 3 * (size_t)i;             // zz = 0 slice positions for every zz
+        const float dx = p[0] - cam->cam_pos[0], dy = p[1] - cam->cam_pos[1], dz = p[2] - cam->cam_pos[2];
+        key[i] = (dx * dx + dy * dy) + dz * dz;
+    }
+    std::vector<int> idx(nxy);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+    for (int r = 0; r < nxy; ++r) rank[idx[r]] = r;
+}
+
+void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k)
+{
+    const GridConsts& g = c->g;
+    std::memset(k, 0, sizeof *k);
+    k->W = c->cfg.width; k->H = c->cfg.height;
+    k->Nx = g.Nx; k->Ny = g.Ny; k->Nz = g.Nz; k->nv = g.nv; k->z0 = g.z0; k->z1 = g.z1;
+    k->zB = hl_z_boundary(c, cam);
+    k->steps = rp->steps_per_mv; k->soft = rp->soft_distance;
+    k->aspect = (float)k->W / (float)k->H;                                   // RM.shader:190
+    k->neg_inv_tan = -(1.0f / (float)std::tan((double)cam->fov_y * 0.5));    // RM.shader:193
+    const float* w2c = cam->world_to_camera;
+    const float csOz = ((cm(w2c, 2, 0) * g.gc[0] + cm(w2c, 2, 1) * g.gc[1]) + cm(w2c, 2, 2) * g.gc[2]) + cm(w2c, 2, 3);
+    const float maxDim = (float)std::max(g.Nx, std::max(g.Ny, g.Nz));
+    const float halfZ = 1.73205f * 0.5f * maxDim * g.s;                      // RM.shader:207
+    k->zMin = csOz + halfZ;                                                  // RM.shader:208
+    k->s = g.s;
+    const float total = maxDim * (float)rp->steps_per_mv;                    // RM.shader:220
+    k->mvStep = ((2.0f * halfZ) * (1.0f / g.s)) * (1.0f / total);            // RM.shader:221-223
+    k->inv_mvStep = 1.0f / k->mvStep;
+    k->nearc = cam->near_clip;
+    k->farc = cam->far_clip > 0.f ? cam->far_clip : 3.0e38f;
+    // _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld (VPR.cs:774-778).  Its linear part is
+    // the same for every MV; the per-MV translation column is finished on the device (k_mv_trans).
+    {
+        const float inv = 1.0f / g.s;
+        for (int r = 0; r < 3; ++r)
+            for (int j = 0; j < 3; ++j) k->inv_rows[r * 3 + j] = g.Rl[j * 3 + r] * inv;
+        const float* B = cam->camera_to_world;
+        for (int r = 0; r < 3; ++r)
+            for (int col = 0; col < 3; ++col)
+                k->c2m_lin[r * 3 + col] = (k->inv_rows[r * 3 + 0] * cm(B, 0, col) + k->inv_rows[r * 3 + 1] * cm(B, 1, col)) +
+                                          k->inv_rows[r * 3 + 2] * cm(B, 2, col);
+        for (int j = 0; j < 4; ++j) k->c2w_t[j] = cm(B, j, 3);
+    }
+    // camera space -> grid space: g = Rl^T (C2W p - mvPos[0,0,0]) / s + 0.5, evaluated in double (traversal only).
+    const float* c2w = cam->camera_to_world;
+    const float* p0 = c->h_mvPos;
+    for (int r = 0; r < 3; ++r) {
+        for (int col = 0; col < 3; ++col) {
+            double acc = 0.0;
+            for (int j = 0; j < 3; ++j) acc += (double)g.Rl[j * 3 + r] * (double)cm(c2w, j, col);
+            k->c2g[r * 4 + col] = (float)(acc / (double)g.s);
+        }
+        double acc = 0.0;
+        for (int j = 0; j < 3; ++j) acc += (double)g.Rl[j * 3 + r] * ((double)cm(c2w, j, 3) - (double)p0[j]);
+        k->c2g[r * 4 + 3] = (float)(acc / (double)g.s + 0.5);
+        k->camg[r] = k->c2g[r * 4 + 3];
+    }
+    k->texScale = (float)(g.nv - 2 * g.b);      // tc = (p + 0.5)(1 - 2b/nv) + b/nv; texel = tc*nv - 0.5   RM.shader:255-258
+    k->texBias = (float)g.b - 0.5f;
+    k->inv_soft = 1.0f / (float)rp->soft_distance;                           // rcp(_SoftDistance)       RM.shader:269
+    k->alpha_cutoff = 0.0f;
+}

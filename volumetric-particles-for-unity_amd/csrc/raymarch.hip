@@ -1,0 +1,344 @@
+// raymarch.hip -- the RayMarch pass + inter-metavoxel blending as ONE launch, one thread per eye ray.
+//
+// Reference shape (VPR.cs:637-794, RM.shader:14-18,95-302): one DrawMeshNow(cube) per occupied metavoxel
+// (~11k draws); every covered fragment redoes the ray set-up, marches that MV back-to-front on a ray lattice
+// that is global per ray, and the ROP blends the MV's premultiplied result into particlesRT with OVER
+// (zz <= zBoundary, (x,y) far->near) or UNDER (zz > zBoundary, near->far).
+//
+// CDNA4 shape: a wave owns an 8x8 pixel tile (neighbouring rays hit the same bricks -> L1/L2 reuse; the final
+// float4 store is eight 128-byte lines).  Each thread sets its ray up once in "grid space" (MV (x,y,z) spans
+// [x,x+1)^3, light-aligned), then walks the light-axis slabs zz ascending -- the reference's major draw order
+// for both phases -- and inside a slab visits the (x,y) cells its ray crosses in the reference's sorted order
+// (rank table built on the host from the same keys as SortMetavoxelSlicesFarToNearFromEye).  Per MV it runs the
+// reference's back-to-front sample loop with software trilinear filtering of the RGBA16F brick (no image
+// hardware on gfx950) and applies the reference's blend equation in registers.  Rays stop once the UNDER phase
+// has saturated (1 - dst.a == 0: every later blend is an exact no-op).
+// Bound: compulsory HBM traffic is one read of every contributing brick + one image store; the sampling itself
+// is L1/L2-resident (64 B requested per sample).
+#include "vpfx_internal.h"
+
+namespace {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+struct F4 { float x, y, z, w; };
+
+__device__ __forceinline__ F4 unpack_texel(uint2 u)
+{
+    const half2_t a = __builtin_bit_cast(half2_t, u.x), b = __builtin_bit_cast(half2_t, u.y);
+    return F4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+}
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
+__device__ __forceinline__ F4 lerp4(const F4& a, const F4& b, float t)
+{
+    return F4{lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)};
+}
+
+struct RayCtx {
+    float ogx, ogy, ogz;      // ray origin (csAABBStart) in grid space               (traversal only)
+    float dgx, dgy, dgz;      // normalised direction in grid space                     (traversal only)
+    float ivx, ivy, ivz;      // 1/dg
+    float lx, ly, lz;         // linear part of mvRay.o = C2M_linear * csAABBStart      RM.shader:216
+    float dx, dy, dz;         // mvRay.d = normalize(C2M_linear * csRayDir)             RM.shader:217
+    float idx, idy, idz;      // 1 / mvRay.d                                            RM.shader:99
+    float startz, dirz;       // camera-space z of origin / direction (for the clip + depth tests)
+    float sceneDepth;
+    int tCameraG;             // camera lattice index estimated in grid space (traversal clamp only)
+};
+
+// One metavoxel for one ray: RM.shader frag (166-302), arithmetic as the reference lays it out: the ray is
+// expressed in THIS metavoxel's unit-cube space through _CameraToMetavoxel (mv translation column `tr`), so
+// tEntry / tExit / tCamera are bit-identical to the per-draw values.  Returns false when the rasteriser would
+// not have produced a fragment (or the shader's own box test misses); src is premultiplied (rgb, 1 - T).
+template <int NV>
+__device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, const uint2* __restrict__ brick, const float4 tr,
+                                         F4& src, int& nsamp)
+{
+    const float ox = R.lx + tr.x, oy = R.ly + tr.y, oz = R.lz + tr.z;                     // mvRay.o :216
+    // IntersectBox(mvRay, -0.5, 0.5)                                                      RM.shader:95-118
+    const float tbx = R.idx * (-0.5f - ox), tby = R.idy * (-0.5f - oy), tbz = R.idz * (-0.5f - oz);
+    const float ttx = R.idx * (0.5f - ox), tty = R.idy * (0.5f - oy), ttz = R.idz * (0.5f - oz);
+    const float tminx = fminf(ttx, tbx), tminy = fminf(tty, tby), tminz = fminf(ttz, tbz);
+    const float tmaxx = fmaxf(ttx, tbx), tmaxy = fmaxf(tty, tby), tmaxz = fmaxf(ttz, tbz);
+    const float t1 = fmaxf(fmaxf(tminx, tminy), fmaxf(tminx, tminz));
+    const float t2 = fminf(fminf(tmaxx, tmaxy), fminf(tmaxx, tmaxz));
+    if (t1 > t2) return false;
+    // back-face fragment must survive near/far clipping and ZTest Less                    RM.shader:14
+    const float exitDepth = -(R.startz + R.dirz * (t2 * k.s));
+    if (!(exitDepth > k.nearc) || !(exitDepth <= k.farc) || !(exitDepth < R.sceneDepth)) return false;
+    int tEntry = (int)ceilf(t1 / k.mvStep);                                               // :236
+    const int tExit = (int)floorf(t2 / k.mvStep);                                         // :237
+    const float cx = tr.x - ox, cy = tr.y - oy, cz = tr.z - oz;                           // mvCameraPos - mvRay.o :238
+    const int tCamera = (int)(sqrtf((cx * cx + cy * cy) + cz * cz) / k.mvStep);           // :239
+    tEntry = max(tEntry, tCamera);                                                        // :240
+    float rr = 0.f, rg = 0.f, rb = 0.f, trans = 1.0f;
+    const float bx = ox + 0.5f, by = oy + 0.5f, bz = oz + 0.5f;
+    for (int si = tExit; si >= tEntry; --si) {                                            // back to front :254
+        const float t = (float)si * k.mvStep;
+        // samplePos = (mvRayPos + 0.5)(1 - 2 bo) + bo, texel = samplePos*nv - 0.5        :255-258
+        const float fx = fmaf(fmaf(t, R.dx, bx), k.texScale, k.texBias);
+        const float fy = fmaf(fmaf(t, R.dy, by), k.texScale, k.texBias);
+        const float fz = fmaf(fmaf(t, R.dz, bz), k.texScale, k.texBias);
+        const float x0 = floorf(fx), y0 = floorf(fy), z0 = floorf(fz);
+        const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
+        const int ix0 = (int)x0 & (NV - 1), iy0 = (int)y0 & (NV - 1), iz0 = (int)z0 & (NV - 1);   // wrap = Repeat  VPR.cs:770
+        const int ix1 = (ix0 + 1) & (NV - 1), iy1 = (iy0 + 1) & (NV - 1), iz1 = (iz0 + 1) & (NV - 1);
+        const int r00 = (iz0 * NV + iy0) * NV, r10 = (iz0 * NV + iy1) * NV, r01 = (iz1 * NV + iy0) * NV, r11 = (iz1 * NV + iy1) * NV;
+        const F4 c000 = unpack_texel(brick[r00 + ix0]), c100 = unpack_texel(brick[r00 + ix1]);
+        const F4 c010 = unpack_texel(brick[r10 + ix0]), c110 = unpack_texel(brick[r10 + ix1]);
+        const F4 c001 = unpack_texel(brick[r01 + ix0]), c101 = unpack_texel(brick[r01 + ix1]);
+        const F4 c011 = unpack_texel(brick[r11 + ix0]), c111 = unpack_texel(brick[r11 + ix1]);
+        const F4 a = lerp4(lerp4(c000, c100, wx), lerp4(c010, c110, wx), wy);
+        const F4 b = lerp4(lerp4(c001, c101, wx), lerp4(c011, c111, wx), wy);
+        const F4 c = lerp4(a, b, wz);                                                     // tex3D :262
+        float density = c.w;
+        const int dc = si - tCamera;
+        if (dc < k.soft) density *= (float)dc * k.inv_soft;                               // soft particles :267-270
+        const float bf = __builtin_amdgcn_rcpf(1.0f + density);                           // :272
+        rr = fmaf(bf, rr - c.x, c.x); rg = fmaf(bf, rg - c.y, c.y); rb = fmaf(bf, rb - c.z, c.z);   // lerp(color, result, bf) :274
+        trans *= bf;                                                                      // :275
+    }
+    nsamp += max(0, tExit - tEntry + 1);
+    src = F4{rr, rg, rb, 1.0f - trans};                                                   // :301
+    return true;
+}
+
+// Translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld for every occupied MV
+// (VPR.cs:774-778), same operation order as the matrix product the reference does per draw.
+__global__ void __launch_bounds__(256)
+k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict__ mvPos, int n, float4* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int mi = occ_list[i];
+    const float mx = mvPos[3 * mi], my = mvPos[3 * mi + 1], mz = mvPos[3 * mi + 2];
+    float tr[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float a = k.inv_rows[r * 3], b = k.inv_rows[r * 3 + 1], c = k.inv_rows[r * 3 + 2];
+        const float t = -((a * mx + b * my) + c * mz);
+        tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + c * k.c2w_t[2]) + t * k.c2w_t[3];
+    }
+    out[i] = make_float4(tr[0], tr[1], tr[2], 0.f);
+}
+
+// PARTIAL = false: the reference's single render target.  PARTIAL = true: OVER-phase and UNDER-phase MVs of the
+// owned slab composite into two separate images (multi-GPU partial images).
+template <int NV, bool PARTIAL>
+__global__ void __launch_bounds__(256)
+k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
+           const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
+           unsigned long long* __restrict__ samples, int early_out)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (col >= k.W || row >= k.H) return;
+
+    // ray set-up                                                                          RM.shader:188-224
+    float dx = (2.0f * ((float)col + 0.5f) / (float)k.W) - 1.0f;
+    const float dy = (2.0f * ((float)row + 0.5f) / (float)k.H) - 1.0f;
+    dx *= k.aspect;
+    const float dz = k.neg_inv_tan;
+    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float dirx = dx * inv, diry = dy * inv, dirz = dz * inv;
+    const float st = k.zMin / dirz;
+    const float sx = dirx * st, sy = diry * st, sz = dirz * st;                            // csAABBStart :212
+    RayCtx R;
+    R.ogx = ((k.c2g[0] * sx + k.c2g[1] * sy) + k.c2g[2] * sz) + k.c2g[3];
+    R.ogy = ((k.c2g[4] * sx + k.c2g[5] * sy) + k.c2g[6] * sz) + k.c2g[7];
+    R.ogz = ((k.c2g[8] * sx + k.c2g[9] * sy) + k.c2g[10] * sz) + k.c2g[11];
+    float gx = (k.c2g[0] * dirx + k.c2g[1] * diry) + k.c2g[2] * dirz;
+    float gy = (k.c2g[4] * dirx + k.c2g[5] * diry) + k.c2g[6] * dirz;
+    float gz = (k.c2g[8] * dirx + k.c2g[9] * diry) + k.c2g[10] * dirz;
+    const float ginv = 1.0f / sqrtf((gx * gx + gy * gy) + gz * gz);
+    R.dgx = gx * ginv; R.dgy = gy * ginv; R.dgz = gz * ginv;                               // mvRay.d :217
+    R.ivx = 1.0f / R.dgx; R.ivy = 1.0f / R.dgy; R.ivz = 1.0f / R.dgz;
+    R.startz = sz; R.dirz = dirz;
+    R.sceneDepth = scene_depth ? scene_depth[(size_t)row * k.W + col] : 3.0e38f;
+    {
+        const float cx = k.camg[0] - R.ogx, cy = k.camg[1] - R.ogy, cz = k.camg[2] - R.ogz;
+        R.tCameraG = (int)(sqrtf((cx * cx + cy * cy) + cz * cz) / k.mvStep);
+    }
+    // the ray in metavoxel space, minus the per-MV translation (exactly the reference's per-draw arithmetic)
+    R.lx = (k.c2m_lin[0] * sx + k.c2m_lin[1] * sy) + k.c2m_lin[2] * sz;
+    R.ly = (k.c2m_lin[3] * sx + k.c2m_lin[4] * sy) + k.c2m_lin[5] * sz;
+    R.lz = (k.c2m_lin[6] * sx + k.c2m_lin[7] * sy) + k.c2m_lin[8] * sz;
+    {
+        const float mx = (k.c2m_lin[0] * dirx + k.c2m_lin[1] * diry) + k.c2m_lin[2] * dirz;
+        const float my = (k.c2m_lin[3] * dirx + k.c2m_lin[4] * diry) + k.c2m_lin[5] * dirz;
+        const float mz = (k.c2m_lin[6] * dirx + k.c2m_lin[7] * diry) + k.c2m_lin[8] * dirz;
+        const float minv = 1.0f / sqrtf((mx * mx + my * my) + mz * mz);
+        R.dx = mx * minv; R.dy = my * minv; R.dz = mz * minv;
+        R.idx = 1.0f / R.dx; R.idy = 1.0f / R.dy; R.idz = 1.0f / R.dz;
+    }
+
+    F4 dstA{0.f, 0.f, 0.f, 0.f}, dstB{0.f, 0.f, 0.f, 0.f};                                 // OnPreRender clear  VPR.cs:171
+    int nsamp = 0;
+
+    // ray vs. the owned part of the grid
+    float tg0, tg1;
+    {
+        const float bx0 = R.ivx * (0.f - R.ogx), bx1 = R.ivx * ((float)k.Nx - R.ogx);
+        const float by0 = R.ivy * (0.f - R.ogy), by1 = R.ivy * ((float)k.Ny - R.ogy);
+        const float bz0 = R.ivz * ((float)k.z0 - R.ogz), bz1 = R.ivz * ((float)k.z1 - R.ogz);
+        tg0 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+        tg1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+        tg0 = fmaxf(tg0, ((float)R.tCameraG - 2.0f) * k.mvStep);                           // nothing is sampled behind the camera
+    }
+    const float eps = 1.0e-4f;
+    const int nxy = k.Nx * k.Ny;
+    bool done = !(tg0 <= tg1);
+
+    for (int zz = k.z0; zz < k.z1 && !done; ++zz) {
+        // parameter range of the ray inside slab zz
+        float ta, tb;
+        if (R.dgz != 0.f) {
+            const float a = R.ivz * ((float)zz - R.ogz), b = R.ivz * ((float)(zz + 1) - R.ogz);
+            ta = fmaxf(fminf(a, b), tg0); tb = fminf(fmaxf(a, b), tg1);
+        } else {
+            if ((int)floorf(R.ogz) != zz) continue;
+            ta = tg0; tb = tg1;
+        }
+        if (!(ta <= tb)) continue;
+        const bool over = zz <= k.zB;                                                      // VPR.cs:667 vs :697
+        const int* occ = brick_index + zz * nxy;
+        int last = over ? 0x7fffffff : -1;
+        for (;;) {
+            // select the next occupied cell of this slab in draw order (rank descending for OVER, ascending for UNDER)
+            int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
+            float t = ta;
+            for (int guard = 0; guard < 2 * (k.Nx + k.Ny) + 8; ++guard) {
+                const float tm = t + eps;
+                const float px = fmaf(tm, R.dgx, R.ogx), py = fmaf(tm, R.dgy, R.ogy);
+                const int cx = (int)floorf(px), cy = (int)floorf(py);
+                const float tx = R.dgx > 0.f ? R.ivx * ((float)(cx + 1) - R.ogx) : (R.dgx < 0.f ? R.ivx * ((float)cx - R.ogx) : 3.0e38f);
+                const float ty = R.dgy > 0.f ? R.ivy * ((float)(cy + 1) - R.ogy) : (R.dgy < 0.f ? R.ivy * ((float)cy - R.ogy) : 3.0e38f);
+                if (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) {
+                    const int cell = cy * k.Nx + cx;
+                    if (occ[cell] >= 0) {
+                        const int r = rank[cell];
+                        const bool better = over ? (r < last && r > best_r) : (r > last && r < best_r);
+                        if (better) { best_r = r; best_cell = cell; }
+                    }
+                }
+                t = fmaxf(fminf(tx, ty), t + eps);
+                if (!(t < tb)) break;
+            }
+            if (best_cell < 0) break;
+            last = best_r;
+            const int bi = occ[best_cell];
+            F4 src;
+            if (!march_mv<NV>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+            if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
+                const float ia = 1.0f - src.w;
+                dstA.x = src.x + dstA.x * ia; dstA.y = src.y + dstA.y * ia; dstA.z = src.z + dstA.z * ia; dstA.w = src.w + dstA.w * ia;
+            } else {                            // Blend OneMinusDstAlpha One                                  VPR.cs:688-691
+                F4& d = PARTIAL ? dstB : dstA;
+                const float ia = 1.0f - d.w;
+                d.x = src.x * ia + d.x; d.y = src.y * ia + d.y; d.z = src.z * ia + d.z; d.w = src.w * ia + d.w;
+            }
+        }
+        if (!over && early_out) {
+            const F4& d = PARTIAL ? dstB : dstA;
+            if (1.0f - d.w <= k.alpha_cutoff) done = true;      // every later UNDER blend multiplies by (1 - dst.a) == 0
+        }
+    }
+
+    const size_t pi = (size_t)row * k.W + col;
+    img_over[pi] = make_float4(dstA.x, dstA.y, dstA.z, dstA.w);
+    if (PARTIAL) img_under[pi] = make_float4(dstB.x, dstB.y, dstB.z, dstB.w);
+    if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
+}
+
+// Ordered blend of partial images (slab granularity of VPR.cs:652-711): kinds[i] 0 = OVER, 1 = UNDER.
+#define MAX_PARTIALS 32
+struct BlendArgs { const float4* img[MAX_PARTIALS]; int kind[MAX_PARTIALS]; int n; };
+
+__global__ void __launch_bounds__(256)
+k_blend(BlendArgs a, size_t npix, float4* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < a.n; ++j) {
+        const float4 s = a.img[j][i];
+        if (a.kind[j] == 0) { const float ia = 1.0f - s.w; d.x = s.x + d.x * ia; d.y = s.y + d.y * ia; d.z = s.z + d.z * ia; d.w = s.w + d.w * ia; }
+        else { const float ia = 1.0f - d.w; d.x = s.x * ia + d.x; d.y = s.y * ia + d.y; d.z = s.z * ia + d.z; d.w = s.w * ia + d.w; }
+    }
+    out[i] = d;
+}
+
+// CompositeParticles.shader: Blend One OneMinusSrcAlpha, One One                           Comp.shader:10
+__global__ void __launch_bounds__(256)
+k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, size_t npix)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const float4 s = particles[i];
+    float4 d = scene[i];
+    const float ia = 1.0f - s.w;
+    d.x = s.x + d.x * ia; d.y = s.y + d.y * ia; d.z = s.z + d.z * ia; d.w = s.w + d.w;
+    scene[i] = d;
+}
+
+template <int NV>
+void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
+{
+    const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
+    if (d_under)
+        hipLaunchKernelGGL((k_raymarch<NV, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
+                           c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, early_out);
+    else
+        hipLaunchKernelGGL((k_raymarch<NV, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
+                           c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, early_out);
+}
+
+}  // namespace
+
+int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
+{
+    const int early_out = c->cfg.reserved[1] == 1 ? 0 : 1;     // cfg.reserved[1] = 1 disables the saturation early-out
+    VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
+    const int nocc = c->h_meta.occupied;
+    if ((size_t)nocc > c->mvtrans_cap) {
+        if (c->d_mvtrans) VP_HIP(hipFree(c->d_mvtrans));
+        c->d_mvtrans = nullptr; c->mvtrans_cap = 0;
+        VP_HIP(hipMalloc((void**)&c->d_mvtrans, ((size_t)nocc + nocc / 8 + 16) * sizeof(float4)));
+        c->mvtrans_cap = (size_t)nocc + nocc / 8 + 16;
+    }
+    if (nocc > 0)
+        hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans);
+    VP_HIP(hipEventRecord(c->ev[2][0], c->stream));
+    switch (k.nv) {
+    case 16: launch_rm_nv<16>(c, k, d_over, d_under, early_out); break;
+    case 32: launch_rm_nv<32>(c, k, d_over, d_under, early_out); break;
+    case 64: launch_rm_nv<64>(c, k, d_over, d_under, early_out); break;
+    default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", k.nv);
+    }
+    VP_HIP(hipGetLastError());
+    VP_HIP(hipEventRecord(c->ev[2][1], c->stream));
+    c->ev_valid[2] = true;
+    return VP_OK;
+}
+
+int launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out)
+{
+    if (n > MAX_PARTIALS) return vp_fail(c, VP_ERR_BAD_ARG, "at most %d partial images", MAX_PARTIALS);
+    BlendArgs a{};
+    a.n = n;
+    for (int i = 0; i < n; ++i) { a.img[i] = (const float4*)d_partials[i]; a.kind[i] = kinds[i]; }
+    const size_t npix = (size_t)c->cfg.width * c->cfg.height;
+    hipLaunchKernelGGL(k_blend, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, a, npix, (float4*)d_out);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int launch_composite(vp_ctx* c, const float* d_particles, float* d_scene)
+{
+    const size_t npix = (size_t)c->cfg.width * c->cfg.height;
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float4*)d_particles, (float4*)d_scene, npix);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}

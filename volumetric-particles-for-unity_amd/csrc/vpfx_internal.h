@@ -1,0 +1,164 @@
+// vpfx_internal.h -- shared declarations of libvpfx (context, kernel-constant PODs, launchers).
+// gfx950 only.  Compiled with -ffp-contract=off: FMAs appear only where written as fmaf()/__builtin_fmaf
+// (arithmetic spec).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/vpfx.h"
+
+#define VP_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel-constant PODs (passed by value as kernel arguments -> SGPRs / kernarg segment)
+// ---------------------------------------------------------------------------------------------------
+struct GridConsts {
+    int Nx, Ny, Nz, nv, b, z0, z1, pad0;
+    float s, sb, one, inv_sb;
+    float Linv[12];   // light worldToLocal, rows r: Linv[r*4 + c], c = 3 is the translation
+    float lsO[3];     // light-space grid centre                                   VPR.cs:380
+    float Rl[9];      // light rotation, row-major Rl[r*3 + c]
+    float Rsb[9];     // Rl * sb   (columns of TRS(mvPos, lightRot, sb))           VPR.cs:596
+    float rowsb[9];   // rows of (TRS(mvPos, lightRot, sb))^-1 linear part: rowsb[k*3+j] = Rl[j*3+k]/sb
+    float fwd[3];     // dirLight.transform.forward.normalized                     VPR.cs:535
+    float gc[3];
+};
+
+struct PsysConsts {
+    float L2W[12];    // particle system localToWorld rows
+    float axis[3];    // particleSys.transform.forward (normalised)
+    int   rot_in_radians;
+};
+
+struct FillConsts {
+    float opacity_factor, D, one_minus_D, init_light;
+    float amb[3];
+    int   fade;
+    float bq, inv_a;              // light depth decode: lsSceneDepth = (d - bq) * inv_a   Fill.shader:218-219
+    float camp[3];                // light camera position (gridCenter - fwd * 200)        VPR.cs:365
+    float dstep[3];               // _LightForward * oneVoxelSize                          Fill.shader:183
+    int   cubeS;
+    float half_s, half_s_m05;     // S/2, S/2 - 0.5
+    int   border_index;           // nv - clamp(b, 0, nv-2)                                Fill.shader:229
+};
+
+struct RmConsts {
+    int W, H, Nx, Ny, Nz, nv, z0, z1;
+    int zB, steps, soft, partial;
+    float aspect, neg_inv_tan, zMin, s;
+    float mvStep, inv_mvStep, nearc, farc;
+    float c2m_lin[9];             // linear part of _CameraToMetavoxel (identical for every MV), rows     VPR.cs:778
+    float inv_rows[9];            // linear part of TRS(mvPos, lightRot, s).inverse, rows
+    float c2w_t[4];               // translation column of cameraToWorld (x, y, z, w)
+    float c2g[12];                // camera space -> grid space (MV (x,y,z) spans [x,x+1)...), rows (traversal only)
+    float camg[3];                // camera position in grid space
+    float texScale, texBias;      // texel coordinate = local * (nv - 2b) + (b - 0.5)
+    float inv_soft;
+    float alpha_cutoff;           // early-out once (1 - dst.a) <= cutoff in the UNDER phase (0 = exact only)
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Device-side buffers and context
+// ---------------------------------------------------------------------------------------------------
+struct DevMeta {                  // small device-resident result block, copied to host after the scan
+    int occupied;
+    int pairs;
+    int max_pairs;
+    int unsorted_lists;           // MVs whose list was too long for the in-LDS rank sort
+};
+
+struct vp_ctx {
+    vp_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    GridConsts g{};
+    bool have_frame = false, have_particles = false, binned = false, filled = false, local_done = false;
+
+    // frame
+    float L[16]{}, gc[3]{};
+    float* h_mvPos = nullptr;     // [N^3][3]
+    float* d_mvPos = nullptr;
+
+    // particles
+    int P = 0, P_cap = 0;
+    size_t raw_cap = 0;
+    uint8_t* d_raw = nullptr;     // caller records as uploaded
+    float4* d_ws = nullptr;       // [P] (ws.xyz, size)
+    float* d_rec = nullptr;       // [P][16]
+    vp_particle_layout lay{};
+    PsysConsts psys{};
+
+    // bins
+    size_t n3 = 0;
+    int* d_count = nullptr;       // [N^3]
+    int* d_offsets = nullptr;     // [N^3 + 1]
+    int* d_cursor = nullptr;      // [N^3]
+    int* d_brick_index = nullptr; // [N^3]
+    int* d_occ_list = nullptr;    // [N^3] (first `occupied` valid): MV linear index of brick i
+    int* d_ids_tmp = nullptr;     // [pairs_cap]
+    int* d_ids = nullptr;         // [pairs_cap]
+    size_t pairs_cap = 0;
+    int* d_colorder = nullptr;    // [Nx*Ny] MV columns, heaviest first
+    DevMeta* d_meta = nullptr;
+    DevMeta h_meta{};
+
+    // fill
+    uint2* d_bricks = nullptr;    // [brick_cap][nv^3] RGBA16F
+    size_t brick_cap = 0;
+    float2* d_dens_ao = nullptr;  // split-fill scratch [brick_cap][nv^3]
+    size_t dens_cap = 0;
+    float* d_lightmap = nullptr;  // [(Ny*nv)][(Nx*nv)]
+    float4* d_cubequads = nullptr;// [6][(S+1)][(S+1)] bilinear footprints
+    int cubeS = 0;
+    float* d_depthmap = nullptr;
+    bool have_depthmap = false;
+    FillConsts fc{};
+
+    // raymarch
+    float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
+    size_t mvtrans_cap = 0;
+    int* d_rank = nullptr;        // [Ny*Nx]
+    int* h_rank = nullptr;
+    float* d_image = nullptr;     // [H][W][4]
+    float* d_scene_depth = nullptr;
+    unsigned long long* d_samples = nullptr;
+    long long last_samples = 0;
+
+    hipEvent_t ev[3][2]{};        // per stage start/stop of the dominant kernel
+    bool ev_valid[3] = {false, false, false};
+
+    std::string err;
+};
+
+extern thread_local std::string g_vp_create_error;
+
+int vp_fail(vp_ctx* c, int code, const char* fmt, ...);
+
+#define VP_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return vp_fail(c, e_ == hipErrorOutOfMemory ? VP_ERR_OOM : VP_ERR_HIP, "%s failed: %s (%s:%d)", \
+                           #call, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+// host_logic.cpp
+void   hl_build_grid(vp_ctx* c);                       // GridConsts + mvPos               VPR.cs:139,370-394
+void   hl_build_psys(vp_ctx* c, const float m[16]);
+void   hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p);
+int    hl_z_boundary(const vp_ctx* c, const vp_camera* cam);             //           VPR.cs:642-648
+void   hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank);  //           VPR.cs:613-632
+void   hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k);
+
+// bin.hip
+int  launch_extract(vp_ctx* c);
+int  launch_bin(vp_ctx* c);
+// fill.hip
+int  launch_build_cubequads(vp_ctx* c, const float* d_cube, int S);
+int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
+// raymarch.hip
+int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under);
+int  launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out);
+int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);

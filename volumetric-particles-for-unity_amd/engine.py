@@ -1,0 +1,186 @@
+"""Thin ctypes binding of libvpfx.so (include/vpfx.h).  No compute here, and NO fallback: if the HIP
+library is missing or no GPU is visible this module raises -- it never routes to a CPU implementation.
+
+`Engine` has the same call surface as `oracle.oracle.Oracle` so the parity tests read symmetrically.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libvpfx.so")
+_lib = None
+
+
+class VpfxError(RuntimeError):
+    def __init__(self, what, code, msg):
+        super().__init__(f"{what} -> {abi.STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libvpfx.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.vp_last_error.restype = C.c_char_p
+        L.vp_last_error.argtypes = [C.c_void_p]
+        for name in abi.EXPORTED_SYMBOLS:
+            getattr(L, name)       # AttributeError if the header and the library ever disagree
+        L.vp_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _vp(a):
+    return C.c_void_p(a) if isinstance(a, int) else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One vp_ctx (one GPU, one light-axis slab)."""
+
+    def __init__(self, cfg: abi.vp_config, *, exact: bool = False, early_out: bool = True):
+        self.L = lib()
+        self.h = C.c_void_p()
+        cfg = _copy_cfg(cfg)
+        cfg.reserved[0] = 1 if exact else 0          # IEEE divisions in the fill kernel (bit-parity builds)
+        cfg.reserved[1] = 0 if early_out else 1      # saturation early-out of the ray-march
+        self.cfg = cfg
+        rc = self.L.vp_create(C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise VpfxError("vp_create", rc, self.L.vp_last_error(None).decode())
+        self.N = tuple(cfg.num_mv)
+        self.nv = cfg.num_voxels
+        self.W, self.H = cfg.width, cfg.height
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc:
+            raise VpfxError(what, rc, self.L.vp_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream: int):
+        self._ck(self.L.vp_set_stream(self.h, C.c_void_p(hip_stream)), "vp_set_stream")
+
+    def sync(self):
+        self._ck(self.L.vp_sync(self.h), "vp_sync")
+
+    # -- frame / bin ---------------------------------------------------------------------------------
+    def set_frame(self, light_to_world, grid_center):
+        l = np.ascontiguousarray(light_to_world, dtype=np.float32)
+        g = np.ascontiguousarray(grid_center, dtype=np.float32)
+        self._ck(self.L.vp_set_frame(self.h, _vp(l), _vp(g)), "vp_set_frame")
+
+    def mv_positions(self):
+        out = np.empty((self.N[2], self.N[1], self.N[0], 3), dtype=np.float32)
+        self._ck(self.L.vp_get_mv_positions(self.h, _vp(out)), "vp_get_mv_positions")
+        return out
+
+    def bin(self, particles, layout, psys_local_to_world):
+        p = np.ascontiguousarray(particles)
+        m = np.ascontiguousarray(psys_local_to_world, dtype=np.float32)
+        self._ck(self.L.vp_bin(self.h, _vp(p), C.c_int32(len(p)), C.byref(layout), _vp(m)), "vp_bin")
+
+    def upload_particles(self, particles, layout, psys_local_to_world):
+        p = np.ascontiguousarray(particles)
+        m = np.ascontiguousarray(psys_local_to_world, dtype=np.float32)
+        self._ck(self.L.vp_upload_particles(self.h, _vp(p), C.c_int32(len(p)), C.byref(layout), _vp(m)), "vp_upload_particles")
+
+    def bin_resident(self):
+        self._ck(self.L.vp_bin_resident(self.h), "vp_bin_resident")
+
+    def bin_counts(self):
+        out = np.empty((self.N[2], self.N[1], self.N[0]), dtype=np.int32)
+        self._ck(self.L.vp_read_bincounts(self.h, _vp(out)), "vp_read_bincounts")
+        return out
+
+    def bin_list(self, xx, yy, zz, cap=1 << 16):
+        ids = np.empty(cap, dtype=np.int32)
+        n = C.c_int32(0)
+        self._ck(self.L.vp_read_binlist(self.h, int(xx), int(yy), int(zz), _vp(ids), cap, C.byref(n)), "vp_read_binlist")
+        return ids[: n.value].copy()
+
+    # -- fill ----------------------------------------------------------------------------------------
+    def fill(self, params):
+        self._ck(self.L.vp_fill(self.h, C.byref(params)), "vp_fill")
+
+    def fill_local(self, params, d_tau_out: int):
+        self._ck(self.L.vp_fill_local(self.h, C.byref(params), C.c_void_p(d_tau_out)), "vp_fill_local")
+
+    def fill_finish(self, d_light_in: int | None):
+        self._ck(self.L.vp_fill_finish(self.h, C.c_void_p(d_light_in or 0)), "vp_fill_finish")
+
+    def read_brick(self, xx, yy, zz):
+        out = np.empty((self.nv, self.nv, self.nv, 4), dtype=np.uint16)
+        self._ck(self.L.vp_read_brick(self.h, int(xx), int(yy), int(zz), _vp(out)), "vp_read_brick")
+        return out.view(np.float16)
+
+    def read_lightmap(self):
+        out = np.empty((self.N[1] * self.nv, self.N[0] * self.nv), dtype=np.float32)
+        self._ck(self.L.vp_read_lightmap(self.h, _vp(out)), "vp_read_lightmap")
+        return out
+
+    # -- ray-march -----------------------------------------------------------------------------------
+    def raymarch(self, cam, rp):
+        img = np.empty((self.H, self.W, 4), dtype=np.float32)
+        self._ck(self.L.vp_raymarch(self.h, C.byref(cam), C.byref(rp), _vp(img)), "vp_raymarch")
+        return img
+
+    def raymarch_device(self, cam, rp, d_rgba: int):
+        self._ck(self.L.vp_raymarch_device(self.h, C.byref(cam), C.byref(rp), C.c_void_p(d_rgba)), "vp_raymarch_device")
+
+    def raymarch_partial_device(self, cam, rp, d_over: int, d_under: int) -> int:
+        mask = C.c_int32(0)
+        self._ck(self.L.vp_raymarch_partial_device(self.h, C.byref(cam), C.byref(rp), C.c_void_p(d_over), C.c_void_p(d_under),
+                                                   C.byref(mask)), "vp_raymarch_partial_device")
+        return mask.value
+
+    def blend_partials_device(self, d_partials, kinds, d_out: int):
+        n = len(d_partials)
+        ptrs = (C.c_void_p * n)(*d_partials)
+        k = (C.c_int32 * n)(*kinds)
+        self._ck(self.L.vp_blend_partials_device(self.h, ptrs, k, n, C.c_void_p(d_out)), "vp_blend_partials_device")
+
+    def composite_device(self, d_particles: int, d_scene: int):
+        self._ck(self.L.vp_composite_device(self.h, C.c_void_p(d_particles), C.c_void_p(d_scene)), "vp_composite_device")
+
+    def z_boundary(self, cam):
+        zb = C.c_int32(0)
+        self._ck(self.L.vp_z_boundary(self.h, C.byref(cam), C.byref(zb)), "vp_z_boundary")
+        return zb.value
+
+    # -- stats ---------------------------------------------------------------------------------------
+    def stats(self):
+        st = abi.vp_stats()
+        self._ck(self.L.vp_get_stats(self.h, C.byref(st)), "vp_get_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+
+    def last_kernel_ms(self, stage: int) -> float:
+        ms = C.c_float(0)
+        self._ck(self.L.vp_last_kernel_ms(self.h, stage, C.byref(ms)), "vp_last_kernel_ms")
+        return ms.value
+
+
+def _copy_cfg(cfg):
+    out = abi.vp_config()
+    C.memmove(C.byref(out), C.byref(cfg), C.sizeof(abi.vp_config))
+    return out
