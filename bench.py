@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sparse-volumetric-particle hot path on MI355X.
+
+One "step" = one full pass of the hot path over one batch of synthetic input that is already resident in HBM:
+    bin (particles -> metavoxels)  ->  fill (+ light propagation)  ->  ray-march (+ inter-metavoxel blend).
+
+Workload at N = 1: BASELINE.json configs[2], the configuration its metric is quoted on:
+    32x32x32 metavoxels x 32^3 voxels, 100k particles, 1920x1080 (synthetic scene of SURVEY.md 8(d)).
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME grid split into light-axis slabs
+(BASELINE.json configs[3]) -> strong scaling; two all-gathers per step (slab transmittance, partial images).
+
+Prints ONE JSON line on rank 0.  `value` = (voxels filled + samples ray-marched) per second over the whole job,
+in millions; the two halves are also reported separately.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from vpfx_amd import engine as E, parallel as PAR, scene as S  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def cpu_baseline(sc, threads=0):
+    """Time the CPU oracle (a port of the reference's algorithm; the reference itself is C# + HLSL and cannot run
+    here) on the GPU box's host cores.  Reported, not shipped: this is the only place bench.py touches oracle/."""
+    from oracle import oracle as O
+    o = O.Oracle(sc.config(), threads=threads)
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    t0 = time.perf_counter()
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    t1 = time.perf_counter()
+    o.fill(sc.fill_params())
+    t2 = time.perf_counter()
+    o.raymarch(sc.camera(), sc.raymarch_params())
+    t3 = time.perf_counter()
+    st = o.stats()
+    units = st["voxels_filled"] + st["samples"]
+    return {
+        "value": units / (t3 - t0) / 1e6, "unit": "M(voxels+samples)/s", "cores": threads or O.Oracle.max_threads(),
+        "kind": "port",
+        "sample": f"one full step of {sc.name} (bin {t1 - t0:.3f}s, fill {t2 - t1:.3f}s, raymarch {t3 - t2:.3f}s)",
+        "fill_mvoxels_per_s": st["voxels_filled"] / (t2 - t1) / 1e6,
+        "raymarch_msamples_per_s": st["samples"] / (t3 - t2) / 1e6,
+        "seconds": t3 - t0,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", help="scene name from vpfx_amd.scene.CONFIGS (default: the metric's config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    sc = S.make_scene(args.config)
+    bounds = PAR.slab_bounds(sc.N[2], world)
+    eng = E.Engine(sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0)))
+    eng.set_frame(sc.light_to_world, sc.grid_center)
+    eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
+    pipe = PAR.SlabPipeline(PAR.HipSlabEngine(eng, device), bounds, rank, world)
+    fp_first, fp = sc.fill_params(), sc.fill_params()
+    fp.cubemap = None                                                           # cubemap stays resident after the first fill
+    cam, rp = sc.camera(), sc.raymarch_params()
+
+    def step(first=False):
+        pipe.fill(fp_first if first else fp)
+        return pipe.render(cam, rp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step(first=True)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    barrier()
+    k_fill, k_rm, k_bin = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event durations of the dominant kernels, recorded on the stream they were launched on
+        k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    st = eng.stats()
+    counts = torch.tensor([st["voxels_filled"], st["samples"], st["occupied_mv"], st["pairs"], st["bricks_sampled"]],
+                          dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    voxels, samples, occupied, pairs, bricks_sampled = [float(x) for x in counts.tolist()]
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        nv = sc.nv
+        fill_ms, rm_ms, bin_ms = float(np.mean(k_fill)), float(np.mean(k_rm)), float(np.mean(k_bin))
+        # algorithmic bytes; rank-0 slab for N > 1
+        fill_bytes = st["occupied_mv"] * (8 * nv ** 3 + 8 * nv ** 2) + 84 * st["pairs"]
+        rm_bytes = st["bricks_sampled"] * 8 * nv ** 3 + 16 * sc.width * sc.height
+        roofs = {
+            "fill": {"bound": "hbm", "kernel": "k_fill", "achieved": fill_bytes / (fill_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "bytes_per_launch": fill_bytes, "avg_ms": fill_ms},
+            "raymarch": {"bound": "hbm", "kernel": "k_raymarch", "achieved": rm_bytes / (rm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "bytes_per_launch": rm_bytes, "avg_ms": rm_ms,
+                         "requested_GBps_64B_per_sample": st["samples"] * 64 / (rm_ms * 1e-3) / 1e9},
+        }
+        for r in roofs.values():
+            r["frac"] = r["achieved"] / r["peak"]
+            r["traffic"] = None
+        dom = "fill" if fill_ms >= rm_ms else "raymarch"
+        out = {
+            "metric": "Mvoxels/s filled + Msamples/s raymarched, 32^3x32^3 grid @1080p",
+            "value": (voxels + samples) / (dt / args.steps) / 1e6,
+            "unit": "M(voxels+samples)/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 compute / f16 voxel storage", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {sc.N[0]}x{sc.N[1]}x{sc.N[2]} metavoxels x {nv}^3 voxels, "
+                                   f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
+                       "parallelism": f"zslab{world}", "slabs": bounds if world > 1 else None,
+                       "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
+                       "samples_per_step": int(samples)},
+            "fill_mvoxels_per_s": voxels / (fill_ms * 1e-3) / 1e6 if world == 1 else None,
+            "raymarch_msamples_per_s": samples / (rm_ms * 1e-3) / 1e6 if world == 1 else None,
+            "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms},
+            "roofline": dict(roofs[dom], stage=dom),
+            "roofline_all": roofs,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, args.cpu_threads)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

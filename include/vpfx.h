@@ -50,7 +50,7 @@ typedef struct vp_ctx vp_ctx;
  * CreateResources (VPR.cs:224-281).  Metavoxels are cubes (the reference assumes it, VPR.cs:422). */
 typedef struct vp_config {
     int32_t num_mv[3];        /* numMetavoxelsX, Y, Z                                  VPR.cs:83 */
-    int32_t num_voxels;       /* numVoxelsInMetavoxel (nv): 8, 16, 32 or 64            VPR.cs:85 */
+    int32_t num_voxels;       /* numVoxelsInMetavoxel (nv): 16, 32 or 64               VPR.cs:85 */
     int32_t num_border;       /* numBorderVoxels per end                               VPR.cs:86 */
     float   mv_scale;         /* mvScale.x: world size of one metavoxel                VPR.cs:84 */
     int32_t width, height;    /* Screen.width / height (particlesRT extent)            VPR.cs:228 */
@@ -114,7 +114,8 @@ typedef struct vp_stats {
     int64_t samples;              /* ray-march samples of the last vp_raymarch* call              */
     int64_t brick_bytes;          /* resident brick pool bytes                                    */
     int64_t max_pairs_per_mv;
-    int64_t reserved[5];
+    int64_t bricks_sampled;       /* bricks that contributed >= 1 sample to the last vp_raymarch* call */
+    int64_t reserved[4];
 } vp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

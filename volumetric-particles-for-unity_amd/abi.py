@@ -95,7 +95,8 @@ class vp_stats(C.Structure):
         ("samples", C.c_int64),
         ("brick_bytes", C.c_int64),
         ("max_pairs_per_mv", C.c_int64),
-        ("reserved", C.c_int64 * 5),
+        ("bricks_sampled", C.c_int64),
+        ("reserved", C.c_int64 * 4),
     ]
 
 

@@ -194,7 +194,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_meta, c->d_bricks, c->d_dens_ao,
-                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_mvtrans, c->d_rank, c->d_image, c->d_scene_depth, c->d_samples};
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int s = 0; s < 3; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
     free(c->h_mvPos); free(c->h_rank);
@@ -479,6 +479,17 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
     unsigned long long s = 0;
     VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));
     st->samples = (int64_t)s;
+    if (c->d_brick_hit && c->h_meta.occupied > 0 && c->ev_valid[2]) {
+        const int n = c->h_meta.occupied;
+        int* h = (int*)malloc((size_t)n * sizeof(int));
+        if (!h) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
+        hipError_t e = hipMemcpy(h, c->d_brick_hit, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+        int64_t cnt = 0;
+        for (int i = 0; i < n; ++i) cnt += h[i] ? 1 : 0;
+        free(h);
+        if (e != hipSuccess) return vp_fail(c, VP_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+        st->bricks_sampled = cnt;
+    }
     return VP_OK;
 }
 

@@ -128,7 +128,7 @@ template <int NV, bool PARTIAL>
 __global__ void __launch_bounds__(256)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
-           unsigned long long* __restrict__ samples, int early_out)
+           unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, int early_out)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -229,7 +229,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             last = best_r;
             const int bi = occ[best_cell];
             F4 src;
+            const int ns0 = nsamp;
             if (!march_mv<NV>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+            if (nsamp != ns0) brick_hit[bi] = 1;
             if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
                 const float ia = 1.0f - src.w;
                 dstA.x = src.x + dstA.x * ia; dstA.y = src.y + dstA.y * ia; dstA.z = src.z + dstA.z * ia; dstA.w = src.w + dstA.w * ia;
@@ -288,10 +290,10 @@ void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, i
     const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
     if (d_under)
         hipLaunchKernelGGL((k_raymarch<NV, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
-                           c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, early_out);
+                           c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
     else
         hipLaunchKernelGGL((k_raymarch<NV, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
-                           c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, early_out);
+                           c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, c->d_brick_hit, early_out);
 }
 
 }  // namespace
@@ -307,6 +309,13 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
         VP_HIP(hipMalloc((void**)&c->d_mvtrans, ((size_t)nocc + nocc / 8 + 16) * sizeof(float4)));
         c->mvtrans_cap = (size_t)nocc + nocc / 8 + 16;
     }
+    if ((size_t)nocc > c->brick_hit_cap) {
+        if (c->d_brick_hit) VP_HIP(hipFree(c->d_brick_hit));
+        c->d_brick_hit = nullptr; c->brick_hit_cap = 0;
+        VP_HIP(hipMalloc((void**)&c->d_brick_hit, ((size_t)nocc + nocc / 8 + 16) * sizeof(int)));
+        c->brick_hit_cap = (size_t)nocc + nocc / 8 + 16;
+    }
+    VP_HIP(hipMemsetAsync(c->d_brick_hit, 0, c->brick_hit_cap * sizeof(int), c->stream));
     if (nocc > 0)
         hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans);
     VP_HIP(hipEventRecord(c->ev[2][0], c->stream));

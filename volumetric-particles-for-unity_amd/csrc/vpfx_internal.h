@@ -124,6 +124,8 @@ struct vp_ctx {
     float* d_image = nullptr;     // [H][W][4]
     float* d_scene_depth = nullptr;
     unsigned long long* d_samples = nullptr;
+    int* d_brick_hit = nullptr;   // [brick_hit_cap] set to 1 by the ray-march when a brick contributes a sample
+    size_t brick_hit_cap = 0;
     long long last_samples = 0;
 
     hipEvent_t ev[3][2]{};        // per stage start/stop of the dominant kernel
