@@ -69,7 +69,7 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
 {
     if (p->cubemap) {
         const int S = p->cubemap_size;
-        if (S < 1 || S > 4096) return vp_fail(c, VP_ERR_BAD_ARG, "cubemap_size %d out of range", S);
+        if (S < 1 || S > 1024) return vp_fail(c, VP_ERR_BAD_ARG, "cubemap_size %d out of range", S);
         if (S != c->cubeS) {
             if (c->d_cubequads) VP_HIP(hipFree(c->d_cubequads));
             c->d_cubequads = nullptr;

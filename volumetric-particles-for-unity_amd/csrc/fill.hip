@@ -19,6 +19,8 @@
 //   * the displacement cubemap is pre-expanded to bilinear footprints: one 16-byte load per covered voxel
 //     instead of four texel fetches (gfx950 has no image/sampler hardware).
 // Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernel is ALU-limited well before it.
+#include <cstdlib>
+
 #include "vpfx_internal.h"
 
 namespace {
@@ -66,25 +68,42 @@ struct FillPtrs {
     float* light_out; uint2* bricks; float2* dens_ao;
 };
 
-// compute_voxel_color (Fill.shader:110-135) for a covered voxel; ps = voxel in particle space, d2 = |ps|^2.
+// compute_voxel_color (Fill.shader:110-135) for a covered voxel, split in two pipeline stages so that the one
+// memory access (the cubemap footprint) can be in flight while the next slice is being addressed:
+//   stage 1: texCUBE addressing  -> footprint index + bilinear weights
+//   stage 2: bilinear + displacement + smoothstep -> (density contribution, net displacement)
 template <bool EXACT>
-__device__ __forceinline__ void voxel_color(const FillConsts& f, const float4* __restrict__ quads, float psx, float psy, float psz,
-                                            float d2, float opacity, float& den, float& net)
+__device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx, float psy, float psz, float& tx, float& ty)
 {
-    // texCUBE(_DisplacementTexture, 2*ps).x -- D3D face selection, per-face bilinear, clamp
+    // D3D face selection, per-face bilinear, clamp.  Branch-free: the three major-axis cases differ only in which
+    // component feeds (sc, tc) and with which sign.
     const float ax = fabsf(psx), ay = fabsf(psy), az = fabsf(psz);
-    int face; float ma, sc, tc;
-    if (ax >= ay && ax >= az) { ma = ax; if (psx >= 0.f) { face = 0; sc = -psz; tc = -psy; } else { face = 1; sc = psz; tc = -psy; } }
-    else if (ay >= az)        { ma = ay; if (psy >= 0.f) { face = 2; sc = psx; tc = psz; } else { face = 3; sc = psx; tc = -psz; } }
-    else                      { ma = az; if (psz >= 0.f) { face = 4; sc = psx; tc = -psy; } else { face = 5; sc = -psx; tc = -psy; } }
+    const bool xm = (ax >= ay) && (ax >= az);          // +-X face
+    const bool ym = !xm && (ay >= az);                 // +-Y face
+    const bool px = psx >= 0.f, py = psy >= 0.f, pz = psz >= 0.f;
+    const float ma = xm ? ax : (ym ? ay : az);
+    //      +X: sc=-z tc=-y | -X: sc=+z tc=-y | +Y: sc=+x tc=+z | -Y: sc=+x tc=-z | +Z: sc=+x tc=-y | -Z: sc=-x tc=-y
+    const float sc = xm ? (px ? -psz : psz) : (ym ? psx : (pz ? psx : -psx));
+    const float tc = ym ? (py ? psz : -psz) : -psy;
+    const bool pos = xm ? px : (ym ? py : pz);
+    const int S = f.cubeS, S1 = S + 1;
+    // row base of the face in the footprint table: (face * S1) with face = 2*axis + (pos ? 0 : 1)
+    const int twoS1 = S1 + S1;
+    const int frow = (xm ? 0 : (ym ? twoS1 : twoS1 + twoS1)) + (pos ? 0 : S1);
     float u = 0.f, v = 0.f;
     if (ma > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma); u = sc * inv; v = tc * inv; }
     const float fx = fmaf(u, f.half_s, f.half_s_m05), fy = fmaf(v, f.half_s, f.half_s_m05);
     const float x0 = floorf(fx), y0 = floorf(fy);
-    const float tx = fx - x0, ty = fy - y0;
-    const int S = f.cubeS;
-    const int ix = min(max((int)x0, -1), S - 1), iy = min(max((int)y0, -1), S - 1);
-    const float4 q = quads[(face * (S + 1) + (iy + 1)) * (S + 1) + (ix + 1)];     // (t00, t10, t01, t11)
+    tx = fx - x0; ty = fy - y0;
+    const int ix = min(max((int)x0, -1), S - 1) + 1, iy = min(max((int)y0, -1), S - 1) + 1;     // [0, S]
+    // 24-bit multiply (full rate), 32-bit unsigned offset: (face*S1 + iy)*S1 + ix < 2^24 for S <= 1024
+    return (unsigned)__mul24(frow + iy, S1) + (unsigned)ix;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /* (t00, t10, t01, t11) */, float tx, float ty,
+                                           float d2, float opw, float& den, float& net)
+{
     const float a = fmaf(tx, q.y - q.x, q.x), b = fmaf(tx, q.w - q.z, q.z);
     const float raw = fmaf(ty, b - a, a);
     net = fmaf(f.D, raw, f.one_minus_D);                                          // netDisplacement   :119
@@ -93,7 +112,7 @@ __device__ __forceinline__ void voxel_color(const FillConsts& f, const float4* _
     t = fminf(fmaxf(t, 0.f), 1.f);
     const float base = (t * t) * (3.0f - 2.0f * t);
     den = base * f.opacity_factor;                                                // :127
-    if (f.fade == 1) den *= opacity;                                              // :130-131
+    if (f.fade == 1) den *= opw;                                                  // :130-131
 }
 
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
@@ -166,13 +185,13 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 const float By = fmaf(r6, f.dstep[2], fmaf(r5, f.dstep[1], r4 * f.dstep[0]));
                 const float Bz = fmaf(r10, f.dstep[2], fmaf(r9, f.dstep[1], r8 * f.dstep[0]));
                 // conservative slice interval of this lane's column (culling only; the exact test follows)
-                const float qa = fmaf(Bz, Bz, fmaf(By, By, Bx * Bx));
-                const float qh = fmaf(Az, Bz, fmaf(Ay, By, Ax * Bx));
-                const float qc = fmaf(Az, Az, fmaf(Ay, Ay, Ax * Ax)) - 0.25f;
-                const float disc = fmaf(qh, qh, -qa * qc) + 2.0e-3f * qa;
-                const float inv_a = __builtin_amdgcn_rcpf(qa);
+                const float ka = fmaf(Bz, Bz, fmaf(By, By, Bx * Bx));
+                const float kh = fmaf(Az, Bz, fmaf(Ay, By, Ax * Bx));
+                const float kc = fmaf(Az, Az, fmaf(Ay, Ay, Ax * Ax)) - 0.25f;
+                const float disc = fmaf(kh, kh, -ka * kc) + 2.0e-3f * ka;
+                const float inv_a = __builtin_amdgcn_rcpf(ka);
                 const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * inv_a;
-                const float sc = -qh * inv_a;
+                const float sc = -kh * inv_a;
                 int lo = (int)ceilf(sc - sq), hi = (int)floorf(sc + sq);
                 lo = max(lo, c0); hi = min(hi, c0 + CH - 1);
                 uint32_t m = 0;
@@ -191,10 +210,12 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                     const bool hit = d2 <= 0.25f;                                        // Fill.shader:172,196
                     if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
                     if (hit) {
-                        float den, net;
-                        voxel_color<EXACT>(f, p_cubequads, psx, psy, psz, d2, opacity, den, net);
+                        float tx, ty, den, net;
+                        const unsigned qi = cube_address<EXACT>(f, psx, psy, psz, tx, ty);
+                        cube_shade<EXACT>(f, p_cubequads[qi], tx, ty, d2, opacity, den, net);
                         dens[s] += den;                                                  // :200
-                        ao[s] = fmaxf(ao[s], net);                                       // :201
+                        // ao = max(ao, net) (:201); both are >= 0, so the max of the bit patterns is the float max
+                        ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
                     }
                 }
             }
@@ -297,9 +318,10 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 {
     constexpr int TPM = (NV / 16) * (NV / 16);
     const dim3 grid(c->g.Nx * c->g.Ny * TPM), block(256);
+    static const int dbg_lds = getenv("VPFX_FILL_LDS") ? atoi(getenv("VPFX_FILL_LDS")) : 0;   // occupancy experiments only
     if (mode == 0) {
         if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
-        else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, dbg_lds, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
     } else if (mode == 1) {
         if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
         else       hipLaunchKernelGGL((k_fill<NV, false, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
