@@ -78,8 +78,7 @@ k_extract(const uint8_t* __restrict__ raw, int P, vp_particle_layout lay, PsysCo
         out[k * 4 + 3] = -((rx * wx + ry * wy) + rz * wz);
     }
     out[12] = life / life0;            // mOpacity = lifetime / startLifetime                  VPR.cs:586
-    out[13] = size * 0.5f;             // mRadius                                              VPR.cs:585
-    out[14] = 0.f; out[15] = 0.f;
+    out[13] = 0.f; out[14] = 0.f; out[15] = 0.f;   // per-frame slice step in particle space, filled by k_bin<0>
     float4* dst = reinterpret_cast<float4*>(rec + 16 * (size_t)p);
     dst[0] = make_float4(out[0], out[1], out[2], out[3]);
     dst[1] = make_float4(out[4], out[5], out[6], out[7]);
@@ -91,11 +90,20 @@ k_extract(const uint8_t* __restrict__ raw, int P, vp_particle_layout lay, PsysCo
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restrict__ mvPos,
-      int* __restrict__ count_or_cursor, const int* __restrict__ offsets, int* __restrict__ ids)
+      int* __restrict__ count_or_cursor, const int* __restrict__ offsets, int* __restrict__ ids, float* __restrict__ rec)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const float4 w = ws4[p];
+    if (MODE == 0) {
+        // B = W2P_linear * (_LightForward * oneVoxelSize): how far one slice step moves a voxel in this particle's
+        // space (arithmetic spec 4.4).  Depends on the frame, so it is refreshed with every bin.
+        float* r = rec + 16 * (size_t)p;
+        const float dx = g.fwd[0] * g.one, dy = g.fwd[1] * g.one, dz = g.fwd[2] * g.one;
+        r[13] = fmaf(r[2], dz, fmaf(r[1], dy, r[0] * dx));
+        r[14] = fmaf(r[6], dz, fmaf(r[5], dy, r[4] * dx));
+        r[15] = fmaf(r[10], dz, fmaf(r[9], dy, r[8] * dx));
+    }
     // lsParticlePos = light.worldToLocal * ws                                                  :419
     const float lx = ((g.Linv[0] * w.x + g.Linv[1] * w.y) + g.Linv[2] * w.z) + g.Linv[3];
     const float ly = ((g.Linv[4] * w.x + g.Linv[5] * w.y) + g.Linv[6] * w.z) + g.Linv[7];
@@ -240,7 +248,7 @@ int launch_bin(vp_ctx* c)
     VP_HIP(hipEventRecord(c->ev[0][0], c->stream));
     if (c->P > 0) {
         hipLaunchKernelGGL(k_bin<0>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_count,
-                           (const int*)nullptr, (int*)nullptr);
+                           (const int*)nullptr, (int*)nullptr, c->d_rec);
     }
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1, c->d_offsets,
                        c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
@@ -260,7 +268,7 @@ int launch_bin(vp_ctx* c)
     }
     if (c->P > 0 && pairs > 0) {
         hipLaunchKernelGGL(k_bin<1>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_cursor,
-                           (const int*)c->d_offsets, c->d_ids_tmp);
+                           (const int*)c->d_offsets, c->d_ids_tmp, c->d_rec);
         hipLaunchKernelGGL(k_sort_lists, dim3(c->h_meta.occupied), dim3(256), 0, c->stream, c->d_occ_list, c->d_offsets,
                            (const int*)c->d_ids_tmp, c->d_ids, c->d_meta);
         VP_HIP(hipGetLastError());

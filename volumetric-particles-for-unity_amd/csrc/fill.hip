@@ -95,7 +95,9 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     const float fx = fmaf(u, f.half_s, f.half_s_m05), fy = fmaf(v, f.half_s, f.half_s_m05);
     const float x0 = floorf(fx), y0 = floorf(fy);
     tx = fx - x0; ty = fy - y0;
-    const int ix = min(max((int)x0, -1), S - 1) + 1, iy = min(max((int)y0, -1), S - 1) + 1;     // [0, S]
+    // |sc|, |tc| <= ma, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
+    // the clamp-addressing of the footprint table never needs a min/max here (NaN converts to 0, also in range).
+    const int ix = (int)x0 + 1, iy = (int)y0 + 1;                                             // [0, S]
     // 24-bit multiply (full rate), 32-bit unsigned offset: (face*S1 + iy)*S1 + ix < 2^24 for S <= 1024
     return (unsigned)__mul24(frow + iy, S1) + (unsigned)ix;
 }
@@ -111,8 +113,7 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /
     float t = fdiv<EXACT>(d2q - net, 0.7f * net - net);                           // smoothstep        :126
     t = fminf(fmaxf(t, 0.f), 1.f);
     const float base = (t * t) * (3.0f - 2.0f * t);
-    den = base * f.opacity_factor;                                                // :127
-    if (f.fade == 1) den *= opw;                                                  // :130-131
+    den = (base * f.opacity_factor) * opw;      // :127, :130-131 (opw = 1.0 exactly when _FadeOutParticles is off)
 }
 
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
@@ -176,14 +177,13 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 const int pid = __builtin_amdgcn_readfirstlane(p_ids[off + i]);
                 const float* r = p_rec + 16 * (size_t)pid;
                 const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
-                const float r8 = r[8], r9 = r[9], r10 = r[10], r11 = r[11], opacity = r[12];
+                const float r8 = r[8], r9 = r[9], r10 = r[10], r11 = r[11];
+                const float opacity = (f.fade == 1) ? r[12] : 1.0f;
+                const float Bx = r[13], By = r[14], Bz = r[15];      // W2P_linear * dstep, per particle per frame (k_bin)
                 // ps(s) = A + s*B (arithmetic spec 4.4): A = W2P*(v0,1), B = W2P_linear * dstep
                 const float Ax = fmaf(r2, v0z, fmaf(r1, v0y, fmaf(r0, v0x, r3)));
                 const float Ay = fmaf(r6, v0z, fmaf(r5, v0y, fmaf(r4, v0x, r7)));
                 const float Az = fmaf(r10, v0z, fmaf(r9, v0y, fmaf(r8, v0x, r11)));
-                const float Bx = fmaf(r2, f.dstep[2], fmaf(r1, f.dstep[1], r0 * f.dstep[0]));
-                const float By = fmaf(r6, f.dstep[2], fmaf(r5, f.dstep[1], r4 * f.dstep[0]));
-                const float Bz = fmaf(r10, f.dstep[2], fmaf(r9, f.dstep[1], r8 * f.dstep[0]));
                 // conservative slice interval of this lane's column (culling only; the exact test follows)
                 const float ka = fmaf(Bz, Bz, fmaf(By, By, Bx * Bx));
                 const float kh = fmaf(Az, Bz, fmaf(Ay, By, Ax * Bx));
