@@ -1,0 +1,45 @@
+"""CPU: slab partitioning and the blend plan of the multi-GPU pipeline (pure host logic)."""
+import pytest
+
+from vpfx_amd import parallel as PAR
+
+
+@pytest.mark.parametrize("nz,world", [(32, 1), (32, 2), (32, 4), (32, 8), (8, 8), (10, 3), (64, 8)])
+def test_uniform_slabs_partition_the_axis(nz, world):
+    b = PAR.slab_bounds(nz, world)
+    assert len(b) == world and b[0][0] == 0 and b[-1][1] == nz
+    assert all(z1 > z0 for z0, z1 in b)
+    assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+    assert max(z1 - z0 for z0, z1 in b) - min(z1 - z0 for z0, z1 in b) <= 1
+
+
+def test_too_many_ranks():
+    with pytest.raises(ValueError):
+        PAR.slab_bounds(4, 5)
+
+
+def test_weighted_slabs_balance_work():
+    w = [0, 0, 1, 5, 20, 40, 40, 20, 5, 1, 0, 0]
+    b = PAR.slab_bounds(len(w), 4, w)
+    assert b[0][0] == 0 and b[-1][1] == len(w) and all(z1 > z0 for z0, z1 in b)
+    loads = [sum(w[z0:z1]) for z0, z1 in b]
+    assert max(loads) <= 0.5 * sum(w)
+
+
+@pytest.mark.parametrize("zb", [-1, 0, 3, 7, 15])
+def test_blend_plan_orders_over_then_under(zb):
+    bounds = PAR.slab_bounds(16, 4)
+    plan, straddler = PAR.blend_plan(bounds, zb)
+    kinds = [k for _, _, k in plan]
+    assert kinds == sorted(kinds)                                   # every OVER before every UNDER
+    overs = [r for r, w, k in plan if k == 0]
+    unders = [r for r, w, k in plan if k == 1]
+    assert overs == sorted(overs) and unders == sorted(unders)      # zz ascending inside each phase
+    for r, (z0, z1) in enumerate(bounds):
+        assert (r in overs) == (z0 <= zb)
+        assert (r in unders) == (z1 - 1 > zb)
+    if straddler is not None:
+        z0, z1 = bounds[straddler]
+        assert z0 <= zb < z1 - 1 and straddler in overs and straddler in unders
+    else:
+        assert not (set(overs) & set(unders))

@@ -1,0 +1,177 @@
+"""CPU: analytic known-answer tests of the oracle (no golden data needed) and unit tests of the arithmetic spec."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from vpfx_amd import scene as S
+from oracle import oracle as O
+from oracle.numpy_twin import Twin
+
+
+def engine(sc):
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    return o
+
+
+def test_empty_grid_is_transparent_and_unshadowed():
+    sc = S.make_scene("e", dims=(4, 16, 0, 32, 24))
+    o = engine(sc)
+    o.fill(sc.fill_params())
+    assert o.stats()["occupied_mv"] == 0
+    np.testing.assert_array_equal(o.read_lightmap(), 1.0)
+    img = o.raymarch(sc.camera(), sc.raymarch_params())
+    np.testing.assert_array_equal(img, 0.0)
+    assert o.stats()["samples"] == 0
+
+
+def one_particle_scene(size, D, pos=(0.0, 0.0, 0.0)):
+    sc = S.make_scene("one", dims=(4, 16, 1, 48, 32))
+    sc.particles["position"][0] = pos
+    sc.particles["size"][0] = size
+    sc.particles["rotation"][0] = 33.0
+    sc.displacement_scale = D
+    return sc
+
+
+def test_single_particle_density_closed_form():
+    """_DisplacementScale = 0 => net displacement == 1 => density = opacityFactor * smoothstep(1, 0.7, 4 d^2) (Fill.shader:119-127)."""
+    sc = one_particle_scene(size=4.0, D=0.0)
+    o = engine(sc)
+    o.fill(sc.fill_params())
+    tw = Twin(sc)
+    pos = tw.grid()
+    co = o.bin_counts()
+    assert co.sum() > 0
+    nv, one = sc.nv, tw.one
+    checked = 0
+    for zz, yy, xx in zip(*np.nonzero(co)):
+        brick = o.read_brick(xx, yy, zz).astype(np.float64)
+        px, py, sl = np.meshgrid(np.arange(nv), np.arange(nv), np.arange(nv), indexing="ij")
+        local = np.stack([(px + 0.5 - nv / 2) / nv, (py + 0.5 - nv / 2) / nv, (sl - nv / 2) / nv], -1) * tw.sb   # no +0.5 in z (Q4)
+        world = local @ tw.Rl.T + pos[zz, yy, xx]
+        d2 = ((world - np.zeros(3)) ** 2).sum(-1) / (4.0 ** 2)        # |ps|^2, ps = (v - ws)/size
+        t = np.clip((4 * d2 - 1.0) / (0.7 - 1.0), 0, 1)
+        dens = np.where(d2 <= 0.25, t * t * (3 - 2 * t) * sc.opacity_factor, 0.0)
+        got = brick[..., 3].transpose(2, 1, 0)                        # brick is [slice][py][px]
+        # fp16 storage + voxels sitting exactly on the surface: 1e-3 relative
+        assert np.abs(got - dens).max() <= 5e-4 * sc.opacity_factor / 0.04 + 1e-3 * dens.max()
+        ao = (brick[..., 0].transpose(2, 1, 0) - 0.4 * 0)             # rgb = 0.4 T + ambient * ao, ao in {0, 1}
+        checked += 1
+    assert checked >= 1
+
+
+def test_uniform_density_alpha_is_integer_power():
+    """A huge particle makes every voxel's density opacityFactor (smoothstep saturated): along any ray alpha = 1 - (1+rho)^-n
+    with n the integer sample count (RM.shader:272-275), soft particles disabled."""
+    sc = one_particle_scene(size=400.0, D=0.0)
+    sc.soft_distance = 1
+    o = engine(sc)
+    assert o.stats()["occupied_mv"] == 64                  # bins into every metavoxel
+    o.fill(sc.fill_params())
+    img = o.raymarch(sc.camera(), sc.raymarch_params())
+    rho = float(np.float16(np.float32(sc.opacity_factor)))
+    a = img[..., 3].astype(np.float64)
+    mask = (a > 1e-3) & (a < 0.999)
+    assert mask.sum() > 100
+    n = -np.log1p(-a[mask]) / math.log1p(rho)
+    assert np.abs(n - np.rint(n)).max() < 2e-2
+    assert abs(np.rint(n).sum() - o.stats()["samples"]) <= 2 * (~mask & (a > 0)).sum() * 400   # loose: totals consistent
+
+
+def test_blend_associativity_over_under():
+    rng = np.random.default_rng(5)
+    H, W = 8, 8
+
+    def rnd():
+        a = rng.random((H, W, 1)).astype(np.float32)
+        return np.concatenate([rng.random((H, W, 3)).astype(np.float32) * a, a], -1)
+    s = [rnd() for _ in range(5)]
+    kinds = [0, 0, 1, 1, 1]
+    full = O.blend_partials(W, H, s, kinds)
+    # group (s0,s1) as one OVER partial and (s2,s3,s4) as one UNDER partial, as a slab would
+    a = O.blend_partials(W, H, s[:2], [0, 0])
+    b = O.blend_partials(W, H, s[2:], [1, 1, 1])
+    np.testing.assert_allclose(O.blend_partials(W, H, [a, b], [0, 1]), full, atol=2e-6)
+
+
+def test_composite_formula():
+    rng = np.random.default_rng(6)
+    p = rng.random((4, 4, 4)).astype(np.float32)
+    sc = rng.random((4, 4, 4)).astype(np.float32)
+    out = O.composite(p, sc)
+    np.testing.assert_allclose(out[..., :3], p[..., :3] + sc[..., :3] * (1 - p[..., 3:4]), atol=1e-6)   # Comp.shader:10
+    np.testing.assert_allclose(out[..., 3], p[..., 3] + sc[..., 3], atol=1e-6)
+
+
+def test_sincos_deg_spec():
+    L = O.lib()
+    s, c = C.c_float(), C.c_float()
+    for deg in list(np.linspace(-720, 720, 2881)) + [0.0, 90.0, 180.0, 270.0, 360.0, 45.0, 1e-3]:
+        L.vpo_sincos_deg(C.c_float(deg), C.byref(s), C.byref(c))
+        assert abs(s.value - math.sin(math.radians(deg))) < 3e-7
+        assert abs(c.value - math.cos(math.radians(deg))) < 3e-7
+
+
+def test_f16_conversion_matches_ieee_rne():
+    L = O.lib()
+    allh = np.arange(65536, dtype=np.uint16)
+    f = allh.view(np.float16).astype(np.float32)
+    for h in range(0, 65536, 7):
+        v = L.vpo_f16_to_f32(h)
+        assert (math.isnan(v) and math.isnan(f[h])) or v == f[h]
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.normal(size=2000) * 10.0 ** rng.integers(-8, 5, 2000), [0.0, -0.0, 65504.0, 65520.0, 1e-8, 6e-8, 6.1e-5]]).astype(np.float32)
+    for x in xs:
+        assert L.vpo_f32_to_f16(C.c_float(float(x))) == int(np.float32(x).astype(np.float16).view(np.uint16))
+
+
+def test_cubemap_sampling_matches_twin():
+    sc = S.make_scene("T0")
+    tw = Twin(sc)
+    L = O.lib()
+    rng = np.random.default_rng(8)
+    d = rng.normal(size=(500, 3))
+    d[:6] = np.eye(3).repeat(2, axis=0) * np.array([1, -1, 1, -1, 1, -1])[:, None]
+    ref = tw._cube(d)
+    cube = np.ascontiguousarray(sc.cubemap)
+    for i in range(len(d)):
+        v = L.vpo_sample_cubemap(cube.ctypes.data, cube.shape[1], float(d[i, 0]), float(d[i, 1]), float(d[i, 2]))
+        assert abs(v - ref[i]) < 2e-5
+
+
+def test_light_depth_map_occluder_kills_light():
+    """An occluder plane in the light depth map: voxels behind it get no direct light (Fill.shader:233-237) and the
+    light map keeps the last unshadowed value."""
+    sc = one_particle_scene(size=400.0, D=0.0)
+    nv, N = sc.nv, sc.N[0]
+    o = engine(sc)
+    o.fill(sc.fill_params())
+    free = o.read_lightmap().copy()
+    # depth such that the scene surface cuts the grid in half along the light axis: light cam is 200 in front of the centre
+    d = np.full((N * nv, N * nv), (200.0 - 0.3) / (1000.0 - 0.3), dtype=np.float32)
+    sc.light_depth_map = d
+    o2 = engine(sc)
+    o2.fill(sc.fill_params())
+    lm = o2.read_lightmap()
+    assert (lm >= free - 1e-7).all() and lm.mean() > free.mean() * 1.5     # light stops being attenuated once shadowed
+    far = o2.read_brick(1, 1, N - 1).astype(np.float32)                     # farthest slab: fully shadowed
+    amb = 0.2 * 1.0
+    np.testing.assert_allclose(far[..., :3], amb, atol=2e-3)                # rgb = 0.4*0 + ambient*ao(=1)
+    near = o2.read_brick(1, 1, 0).astype(np.float32)
+    assert near[0, :, :, 0].max() > amb + 0.3                               # lit at the light-facing side
+
+
+def test_scene_depth_rejects_metavoxels_behind_geometry():
+    sc = S.make_scene("T0")
+    o = engine(sc)
+    o.fill(sc.fill_params())
+    full = o.raymarch(sc.camera(), sc.raymarch_params())
+    sc.scene_depth = np.full((sc.height, sc.width), 0.31, dtype=np.float32)    # wall right in front of the camera
+    none = o.raymarch(sc.camera(), sc.raymarch_params())
+    np.testing.assert_array_equal(none, 0.0)
+    sc.scene_depth = np.full((sc.height, sc.width), 1e6, dtype=np.float32)
+    np.testing.assert_array_equal(o.raymarch(sc.camera(), sc.raymarch_params()), full)
