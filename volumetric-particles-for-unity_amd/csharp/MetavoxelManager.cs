@@ -1,0 +1,212 @@
+// MetavoxelManager.cs -- the reference-side binding: a Unity C# component that keeps the entry points of
+// MetavoxelEngine.VolumetricParticleRenderer (Assets/Main Scene/VolumetricParticleRenderer.cs) for the hot path and
+// forwards them to libvpfx through P/Invoke (include/vpfx.h).
+//
+// SOURCE ONLY: this container has no C# toolchain (no mono / mcs / dotnet) and Unity is closed source, so this file
+// is not compiled or tested here; tests exercise the identical call sequence through the Python mirror
+// (volumetric-particles-for-unity_amd/manager.py) over the same C ABI.
+//
+// What it replaces in the reference (nothing else of the component changes):
+//   BinParticlesToMetavoxels()   VPR.cs:397-457   -> vp_bin
+//   FillMetavoxels()/FillMetavoxel VPR.cs:495-609 -> vp_fill   (no per-MV ComputeBuffer / Blit any more)
+//   RenderMetavoxels()/RenderMetavoxel VPR.cs:637-794 -> vp_raymarch (no per-MV DrawMeshNow / ROP blend)
+//   UpdateMetavoxelPositions()   VPR.cs:370-394   -> vp_set_frame
+using System;
+using System.Runtime.InteropServices;
+using UnityEngine;
+
+namespace MetavoxelEngine
+{
+    [RequireComponent(typeof(Camera))]
+    public class MetavoxelManager : MonoBehaviour
+    {
+        // ---- inspector fields: same names as VolumetricParticleRenderer (VPR.cs:72-101) -----------------
+        public Light dirLight;
+        public ParticleSystem particleSys;
+        public Cubemap displacementTexture;
+        public GameObject gridCenter;
+        public int numMetavoxelsX = 10, numMetavoxelsY = 10, numMetavoxelsZ = 10;
+        public Vector3 mvScale = new Vector3(3, 3, 3);
+        public int numVoxelsInMetavoxel = 32;
+        public int numBorderVoxels = 1;
+        public int updateInterval = 2;
+        public int rayMarchSteps = 64;
+        public Vector3 ambientColor = new Vector3(0.2f, 0.2f, 0.2f);
+        public float fDisplacementScale = 0.7f;
+        public bool fadeOutParticles = false;
+        public float opacityFactor = 0.04f;
+        public int softParticleStepDistance = 20;
+
+        // ---- C ABI (include/vpfx.h) ---------------------------------------------------------------------
+        [StructLayout(LayoutKind.Sequential)]
+        struct vp_config
+        {
+            public int nx, ny, nz, num_voxels, num_border; public float mv_scale;
+            public int width, height, device, slab_z0, slab_z1;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 5)] public int[] reserved;
+        }
+        [StructLayout(LayoutKind.Sequential)]
+        struct vp_particle_layout
+        {
+            public int stride, off_position, off_size, off_rotation, off_lifetime, off_start_lifetime, rotation_in_radians, reserved;
+        }
+        [StructLayout(LayoutKind.Sequential)]
+        struct vp_fill_params
+        {
+            public float opacity_factor, displacement_scale; public int fade_out_particles;
+            public float ambient_r, ambient_g, ambient_b, init_light_intensity, light_near, light_far, light_cam_distance;
+            public int cubemap_size, reserved;
+            public IntPtr cubemap, light_depth_map;
+        }
+        [StructLayout(LayoutKind.Sequential)]
+        struct vp_camera
+        {
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] world_to_camera;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] camera_to_world;
+            public float px, py, pz, fov_y, near_clip, far_clip;
+        }
+        [StructLayout(LayoutKind.Sequential)]
+        struct vp_raymarch_params
+        {
+            public int steps_per_mv, soft_distance; public IntPtr scene_depth;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public int[] reserved;
+        }
+
+        const string LIB = "vpfx";
+        [DllImport(LIB)] static extern int vp_create(ref vp_config cfg, out IntPtr ctx);
+        [DllImport(LIB)] static extern void vp_destroy(IntPtr ctx);
+        [DllImport(LIB)] static extern IntPtr vp_last_error(IntPtr ctx);
+        [DllImport(LIB)] static extern int vp_set_frame(IntPtr ctx, float[] lightToWorld, float[] gridCenter);
+        [DllImport(LIB)] static extern int vp_bin(IntPtr ctx, IntPtr particles, int count, ref vp_particle_layout layout, float[] psysLocalToWorld);
+        [DllImport(LIB)] static extern int vp_fill(IntPtr ctx, ref vp_fill_params p);
+        [DllImport(LIB)] static extern int vp_raymarch(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, IntPtr rgbaOut);
+
+        IntPtr ctx = IntPtr.Zero;
+        ParticleSystem.Particle[] parts;
+        float[] cubemapR;              // .x channel of the displacement cubemap, faces +X,-X,+Y,-Y,+Z,-Z, row 0 = top
+        bool cubemapResident = false;
+        float[] rgba;                  // particlesRT as float RGBA (premultiplied), row 0 = bottom
+        Texture2D particlesTex;
+        Quaternion lightOrientation;
+        Vector3 wsGridCenter;
+
+        static float[] ToArray(Matrix4x4 m)   // Unity Matrix4x4 is column-major in memory: m00,m10,m20,m30,m01,...
+        {
+            var a = new float[16];
+            for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) a[c * 4 + r] = m[r, c];
+            return a;
+        }
+
+        void Check(int rc, string what)
+        {
+            // the reference logs and carries on (VPR.cs:352,790); so do we
+            if (rc != 0) Debug.LogError(what + " failed (" + rc + "): " + Marshal.PtrToStringAnsi(vp_last_error(ctx)));
+        }
+
+        void Start()                                                       // VPR.cs:132-149
+        {
+            var cfg = new vp_config {
+                nx = numMetavoxelsX, ny = numMetavoxelsY, nz = numMetavoxelsZ, num_voxels = numVoxelsInMetavoxel,
+                num_border = numBorderVoxels, mv_scale = mvScale.x, width = Screen.width, height = Screen.height,
+                device = -1, slab_z0 = 0, slab_z1 = 0, reserved = new int[5] };
+            int rc = vp_create(ref cfg, out ctx);
+            if (rc != 0) { Debug.LogError("vp_create failed (" + rc + "): " + Marshal.PtrToStringAnsi(vp_last_error(IntPtr.Zero))); return; }
+            parts = new ParticleSystem.Particle[particleSys.maxParticles];
+            rgba = new float[Screen.width * Screen.height * 4];
+            particlesTex = new Texture2D(Screen.width, Screen.height, TextureFormat.RGBAFloat, false);
+            int S = displacementTexture.width;
+            cubemapR = new float[6 * S * S];
+            CubemapFace[] faces = { CubemapFace.PositiveX, CubemapFace.NegativeX, CubemapFace.PositiveY,
+                                    CubemapFace.NegativeY, CubemapFace.PositiveZ, CubemapFace.NegativeZ };
+            for (int f = 0; f < 6; f++)
+            {
+                Color[] px = displacementTexture.GetPixels(faces[f]);
+                for (int i = 0; i < S * S; i++) cubemapR[f * S * S + i] = px[i].r;
+            }
+            lightOrientation = dirLight.transform.rotation;
+            wsGridCenter = gridCenter.transform.position;
+            UpdateMetavoxelPositions();
+        }
+
+        void OnDestroy() { if (ctx != IntPtr.Zero) { vp_destroy(ctx); ctx = IntPtr.Zero; } }
+
+        void OnPostRender()                                                // VPR.cs:181-220
+        {
+            if (ctx == IntPtr.Zero) return;
+            if (Time.frameCount % updateInterval == 0)
+            {
+                if (dirLight.transform.rotation != lightOrientation || wsGridCenter != gridCenter.transform.position)
+                {
+                    lightOrientation = dirLight.transform.rotation;
+                    wsGridCenter = gridCenter.transform.position;
+                    UpdateMetavoxelPositions();
+                }
+                BinParticlesToMetavoxels();
+                FillMetavoxels();
+            }
+            RenderMetavoxels();
+            // particlesTex now holds the ray-marched volume; composite it exactly as the reference does (VPR.cs:210,
+            // CompositeParticles.shader: Blend One OneMinusSrcAlpha, One One).
+        }
+
+        void UpdateMetavoxelPositions()                                    // VPR.cs:370-394
+        {
+            Vector3 g = wsGridCenter;
+            Check(vp_set_frame(ctx, ToArray(dirLight.transform.localToWorldMatrix), new float[] { g.x, g.y, g.z }), "vp_set_frame");
+        }
+
+        void BinParticlesToMetavoxels()                                    // VPR.cs:397-457
+        {
+            int n = particleSys.GetParticles(parts);
+            // explicit field offsets: the managed layout of ParticleSystem.Particle is Unity-version specific
+            var lay = new vp_particle_layout {
+                stride = Marshal.SizeOf(typeof(ParticleSystem.Particle)),
+                off_position = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Position"),
+                off_size = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Size"),
+                off_rotation = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Rotation"),
+                off_lifetime = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Lifetime"),
+                off_start_lifetime = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_StartLifetime"),
+                rotation_in_radians = 1 /* the raw field is radians; the .rotation property converts to degrees */ };
+            GCHandle h = GCHandle.Alloc(parts, GCHandleType.Pinned);       // zero-copy view; the library keeps no pointer
+            try { Check(vp_bin(ctx, h.AddrOfPinnedObject(), n, ref lay, ToArray(particleSys.transform.localToWorldMatrix)), "vp_bin"); }
+            finally { h.Free(); }
+        }
+
+        void FillMetavoxels()                                              // VPR.cs:495-609 (+ SetFillPassConstants :523-554)
+        {
+            var p = new vp_fill_params {
+                opacity_factor = opacityFactor, displacement_scale = fDisplacementScale, fade_out_particles = fadeOutParticles ? 1 : 0,
+                ambient_r = ambientColor.x, ambient_g = ambientColor.y, ambient_b = ambientColor.z, init_light_intensity = 1.0f,
+                light_near = 0.3f, light_far = 1000f, light_cam_distance = 200f, cubemap_size = displacementTexture.width,
+                cubemap = IntPtr.Zero, light_depth_map = IntPtr.Zero /* no occluders; pass the light depth map here when rendered */ };
+            GCHandle h = default(GCHandle);
+            if (!cubemapResident) { h = GCHandle.Alloc(cubemapR, GCHandleType.Pinned); p.cubemap = h.AddrOfPinnedObject(); }
+            try { Check(vp_fill(ctx, ref p), "vp_fill"); cubemapResident = true; }
+            finally { if (h.IsAllocated) h.Free(); }
+        }
+
+        public void RenderMetavoxels()                                     // VPR.cs:637-794 (+ SetRaymarchPassConstants :716-763)
+        {
+            Camera c = Camera.main;
+            Vector3 cp = c.transform.position;
+            var cam = new vp_camera {
+                world_to_camera = ToArray(c.worldToCameraMatrix), camera_to_world = ToArray(c.cameraToWorldMatrix),
+                px = cp.x, py = cp.y, pz = cp.z, fov_y = Mathf.Deg2Rad * c.fieldOfView, near_clip = c.nearClipPlane, far_clip = c.farClipPlane };
+            var rp = new vp_raymarch_params { steps_per_mv = rayMarchSteps, soft_distance = softParticleStepDistance,
+                                              scene_depth = IntPtr.Zero, reserved = new int[4] };
+            GCHandle h = GCHandle.Alloc(rgba, GCHandleType.Pinned);
+            try { Check(vp_raymarch(ctx, ref cam, ref rp, h.AddrOfPinnedObject()), "vp_raymarch"); }
+            finally { h.Free(); }
+            particlesTex.SetPixelData(rgba, 0);
+            particlesTex.Apply(false);
+        }
+
+        // GUI setters (VPR.cs:1040-1119) keep their names
+        public void SetOpacityFactor(float v) { opacityFactor = v; }
+        public void SetDisplacementScale(float v) { fDisplacementScale = v; }
+        public void SetRayMarchSteps(float v) { rayMarchSteps = (int)v; }
+        public void SetSoftParticleStepDistance(float v) { softParticleStepDistance = (int)v; }
+        public void SetUpdateInterval(float v) { updateInterval = Mathf.Max(1, (int)v); }
+        public void SetFadeOutParticles(bool v) { fadeOutParticles = v; }
+    }
+}
