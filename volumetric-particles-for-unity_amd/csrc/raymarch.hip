@@ -28,10 +28,27 @@ __device__ __forceinline__ F4 unpack_texel(uint2 u)
     const half2_t a = __builtin_bit_cast(half2_t, u.x), b = __builtin_bit_cast(half2_t, u.y);
     return F4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
 }
+// A texel pair (x0, x0+1) of one brick row: 16 bytes = {r0|g0, b0|a0, r1|g1, b1|a1} as packed halves.
+struct __attribute__((aligned(8))) TexelPair { uint32_t rg0, ba0, rg1, ba1; };
+
+// a + w (b - a) with a, b fp16 (low or high half of a dword) and f32 arithmetic, as two v_fma_mix_f32: the mixed-
+// precision FMA reads the packed halves directly, so no v_cvt_f32_f16 / unpacking is spent on the 32 texel values.
+//   tmp = -w * a + a ;  d = w * b + tmp
+#define VPFX_MIX_LERP(HI)                                                                                          \
+    asm("v_fma_mix_f32 %0, -%1, %2, %2 op_sel:[0," #HI "," #HI "] op_sel_hi:[0,1,1]" : "=v"(tmp) : "v"(w), "v"(a)); \
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0," #HI ",0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(b), "v"(tmp));
+__device__ __forceinline__ float mix_lerp_lo(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(0) return d; }
+__device__ __forceinline__ float mix_lerp_hi(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(1) return d; }
+
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 __device__ __forceinline__ F4 lerp4(const F4& a, const F4& b, float t)
 {
     return F4{lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)};
+}
+
+__device__ __forceinline__ F4 lerp_x(const TexelPair t, float w)
+{
+    return F4{mix_lerp_lo(w, t.rg0, t.rg1), mix_lerp_hi(w, t.rg0, t.rg1), mix_lerp_lo(w, t.ba0, t.ba1), mix_lerp_hi(w, t.ba0, t.ba1)};
 }
 
 struct RayCtx {
@@ -50,7 +67,7 @@ struct RayCtx {
 // expressed in THIS metavoxel's unit-cube space through _CameraToMetavoxel (mv translation column `tr`), so
 // tEntry / tExit / tCamera are bit-identical to the per-draw values.  Returns false when the rasteriser would
 // not have produced a fragment (or the shader's own box test misses); src is premultiplied (rgb, 1 - T).
-template <int NV>
+template <int NV, bool WRAP>
 __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, const uint2* __restrict__ brick, const float4 tr,
                                          F4& src, int& nsamp)
 {
@@ -81,16 +98,29 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
         const float fz = fmaf(fmaf(t, R.dz, bz), k.texScale, k.texBias);
         const float x0 = floorf(fx), y0 = floorf(fy), z0 = floorf(fz);
         const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
-        const int ix0 = (int)x0 & (NV - 1), iy0 = (int)y0 & (NV - 1), iz0 = (int)z0 & (NV - 1);   // wrap = Repeat  VPR.cs:770
-        const int ix1 = (ix0 + 1) & (NV - 1), iy1 = (iy0 + 1) & (NV - 1), iz1 = (iz0 + 1) & (NV - 1);
-        const int r00 = (iz0 * NV + iy0) * NV, r10 = (iz0 * NV + iy1) * NV, r01 = (iz1 * NV + iy0) * NV, r11 = (iz1 * NV + iy1) * NV;
-        const F4 c000 = unpack_texel(brick[r00 + ix0]), c100 = unpack_texel(brick[r00 + ix1]);
-        const F4 c010 = unpack_texel(brick[r10 + ix0]), c110 = unpack_texel(brick[r10 + ix1]);
-        const F4 c001 = unpack_texel(brick[r01 + ix0]), c101 = unpack_texel(brick[r01 + ix1]);
-        const F4 c011 = unpack_texel(brick[r11 + ix0]), c111 = unpack_texel(brick[r11 + ix1]);
-        const F4 a = lerp4(lerp4(c000, c100, wx), lerp4(c010, c110, wx), wy);
-        const F4 b = lerp4(lerp4(c001, c101, wx), lerp4(c011, c111, wx), wy);
-        const F4 c = lerp4(a, b, wz);                                                     // tex3D :262
+        TexelPair t00, t10, t01, t11;    // [z][y]: texels (x0, x0+1)
+        if (!WRAP) {
+            // border >= 1: the 2x2x2 footprint never leaves the brick (texel coords lie in [b-0.5, nv-b-0.5]), so the
+            // x-neighbours are one 16-byte load and the y / z neighbours fixed offsets from one base address.
+            const int base = ((int)z0 * NV + (int)y0) * NV + (int)x0;
+            const uint2* p = brick + base;
+            t00 = *reinterpret_cast<const TexelPair*>(p);
+            t10 = *reinterpret_cast<const TexelPair*>(p + NV);
+            t01 = *reinterpret_cast<const TexelPair*>(p + NV * NV);
+            t11 = *reinterpret_cast<const TexelPair*>(p + NV * NV + NV);
+        } else {
+            const int ix0 = (int)x0 & (NV - 1), iy0 = (int)y0 & (NV - 1), iz0 = (int)z0 & (NV - 1);   // wrap = Repeat  VPR.cs:770
+            const int ix1 = (ix0 + 1) & (NV - 1), iy1 = (iy0 + 1) & (NV - 1), iz1 = (iz0 + 1) & (NV - 1);
+            const int r00 = (iz0 * NV + iy0) * NV, r10 = (iz0 * NV + iy1) * NV, r01 = (iz1 * NV + iy0) * NV, r11 = (iz1 * NV + iy1) * NV;
+            const uint2 a0 = brick[r00 + ix0], a1 = brick[r00 + ix1], b0 = brick[r10 + ix0], b1 = brick[r10 + ix1];
+            const uint2 c0 = brick[r01 + ix0], c1 = brick[r01 + ix1], d0 = brick[r11 + ix0], d1 = brick[r11 + ix1];
+            t00 = TexelPair{a0.x, a0.y, a1.x, a1.y}; t10 = TexelPair{b0.x, b0.y, b1.x, b1.y};
+            t01 = TexelPair{c0.x, c0.y, c1.x, c1.y}; t11 = TexelPair{d0.x, d0.y, d1.x, d1.y};
+        }
+        // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math),
+        // then y and z in f32.  tex3D :262
+        const F4 c00 = lerp_x(t00, wx), c10 = lerp_x(t10, wx), c01 = lerp_x(t01, wx), c11 = lerp_x(t11, wx);
+        const F4 c = lerp4(lerp4(c00, c10, wy), lerp4(c01, c11, wy), wz);
         float density = c.w;
         const int dc = si - tCamera;
         if (dc < k.soft) density *= (float)dc * k.inv_soft;                               // soft particles :267-270
@@ -124,7 +154,7 @@ k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict
 
 // PARTIAL = false: the reference's single render target.  PARTIAL = true: OVER-phase and UNDER-phase MVs of the
 // owned slab composite into two separate images (multi-GPU partial images).
-template <int NV, bool PARTIAL>
+template <int NV, bool PARTIAL, bool WRAP>
 __global__ void __launch_bounds__(256)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
@@ -230,7 +260,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             const int bi = occ[best_cell];
             F4 src;
             const int ns0 = nsamp;
-            if (!march_mv<NV>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+            if (!march_mv<NV, WRAP>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
                 const float ia = 1.0f - src.w;
@@ -288,11 +318,18 @@ template <int NV>
 void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
 {
     const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
-    if (d_under)
-        hipLaunchKernelGGL((k_raymarch<NV, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
+    const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
+    if (d_under && wrap)
+        hipLaunchKernelGGL((k_raymarch<NV, true, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
+                           c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
+    else if (wrap)
+        hipLaunchKernelGGL((k_raymarch<NV, false, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
+                           c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, c->d_brick_hit, early_out);
+    else if (d_under)
+        hipLaunchKernelGGL((k_raymarch<NV, true, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
                            c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
     else
-        hipLaunchKernelGGL((k_raymarch<NV, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
+        hipLaunchKernelGGL((k_raymarch<NV, false, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
                            c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, c->d_brick_hit, early_out);
 }
 
