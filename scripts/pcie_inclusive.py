@@ -1,0 +1,27 @@
+"""Step time through the host-buffer entry points (vp_bin with host particles, vp_raymarch to a host image)."""
+import sys, time
+sys.path.insert(0, '.')
+from __graft_entry__ import load_package; load_package()
+from vpfx_amd import scene as S, engine as E
+sc = S.make_scene(sys.argv[1] if len(sys.argv) > 1 else "C3")
+e = E.Engine(sc.config()); e.set_frame(sc.light_to_world, sc.grid_center)
+fp0, fp = sc.fill_params(), sc.fill_params(); fp.cubemap = None
+cam, rp = sc.camera(), sc.raymarch_params()
+e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp0); e.raymarch(cam, rp)
+n = 10
+t0 = time.perf_counter()
+for _ in range(n):
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp); img = e.raymarch(cam, rp)
+dt = (time.perf_counter() - t0) / n
+st = e.stats()
+print(f"host-buffer step {dt*1e3:.3f} ms  -> {(st['voxels_filled']+st['samples'])/dt/1e6:.0f} M(voxels+samples)/s")
+t0 = time.perf_counter()
+for _ in range(n):
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+tb = (time.perf_counter() - t0) / n
+e.fill(fp)
+t0 = time.perf_counter()
+for _ in range(n):
+    img = e.raymarch(cam, rp)
+tr = (time.perf_counter() - t0) / n
+print(f"vp_bin (H2D {sc.particles.nbytes/1e6:.1f} MB + bin) {tb*1e3:.3f} ms; vp_raymarch (+ D2H {img.nbytes/1e6:.1f} MB) {tr*1e3:.3f} ms")
