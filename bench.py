@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--config", default="C3", help="scene name from vpfx_amd.scene.CONFIGS (default: the metric's config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="functional test only: all ranks on cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,10 +77,15 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     sc = S.make_scene(args.config)
     bounds = PAR.slab_bounds(sc.N[2], world)
@@ -103,12 +110,14 @@ def main():
     for _ in range(max(args.warmup - 1, 0)):
         step()
     barrier()
-    k_fill, k_rm, k_bin = [], [], []
+    k_fill, k_rm, k_bin, k_fin = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         # HIP-event durations of the dominant kernels, recorded on the stream they were launched on
         k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))
+        if world > 1:
+            k_fin.append(eng.last_kernel_ms(3))
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -153,7 +162,8 @@ def main():
                        "samples_per_step": int(samples)},
             "fill_mvoxels_per_s": voxels / (fill_ms * 1e-3) / 1e6 if world == 1 else None,
             "raymarch_msamples_per_s": samples / (rm_ms * 1e-3) / 1e6 if world == 1 else None,
-            "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms},
+            "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms,
+                         "fill_finish_kernel": float(np.mean(k_fin)) if k_fin else None},
             "roofline": dict(roofs[dom], stage=dom),
             "roofline_all": roofs,
         }

@@ -187,7 +187,8 @@ int  vp_read_brick(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz, uint16_t* ha
 int  vp_read_lightmap(vp_ctx* ctx, float* out /* [(Ny*nv)][(Nx*nv)] */);
 int  vp_get_stats(vp_ctx* ctx, vp_stats* out);
 /* Device time in milliseconds of the dominant kernel of a stage over its most recent launch,
- * measured with HIP events on the context's stream. stage: 0 bin, 1 fill, 2 raymarch. */
+ * measured with HIP events on the context's stream. stage: 0 bin, 1 fill (vp_fill / vp_fill_local), 2 raymarch,
+ * 3 vp_fill_finish. */
 int  vp_last_kernel_ms(vp_ctx* ctx, int32_t stage, float* ms);
 
 #ifdef __cplusplus

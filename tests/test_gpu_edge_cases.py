@@ -1,0 +1,195 @@
+"""GPU parity on the edge cases and option branches of the path (all through the C ABI, all against the oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from vpfx_amd import abi, engine as E, scene as S
+from vpfx_amd.manager import MetavoxelManager
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def both(sc, **kw):
+    o, g = O.Oracle(sc.config()), E.Engine(sc.config(), **kw)
+    for x in (o, g):
+        x.set_frame(sc.light_to_world, sc.grid_center)
+        x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        x.fill(sc.fill_params())
+    return o, g
+
+
+def check(sc, exact=True, rgba_tol=1e-3, **kw):
+    o, g = both(sc, exact=exact, early_out=False, **kw)
+    np.testing.assert_array_equal(o.bin_counts(), g.bin_counts())
+    co = o.bin_counts()
+    for zz, yy, xx in zip(*np.nonzero(co)):
+        a, b = o.read_brick(xx, yy, zz).view(np.uint16), g.read_brick(xx, yy, zz).view(np.uint16)
+        if exact:
+            assert np.array_equal(a, b), (xx, yy, zz)
+        else:
+            assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ig).max() <= rgba_tol
+    assert abs(o.stats()["samples"] - g.stats()["samples"]) <= 1e-4 * o.stats()["samples"] + 8
+    return o, g, io, ig
+
+
+def test_empty_particle_array():
+    sc = S.make_scene("e", dims=(4, 16, 0, 64, 48))
+    o, g, io, ig = check(sc)
+    assert g.stats()["occupied_mv"] == 0
+    np.testing.assert_array_equal(g.read_lightmap(), 1.0)
+    np.testing.assert_array_equal(ig, 0.0)
+
+
+def test_fade_and_radians_and_moved_particle_system():
+    sc = S.make_scene("x", dims=(6, 16, 300, 96, 64), rotation_in_radians=True, fade=1)
+    rot = S.quat_to_matrix((0.1, 0.3, -0.2, 0.927))
+    sc.psys_local_to_world = S.to_colmajor16(S.trs((0.7, -0.4, 1.1), rot))
+    sc.grid_center = np.array([0.5, -0.25, 0.75], dtype=np.float32)
+    check(sc)
+
+
+@pytest.mark.parametrize("dims", [(5, 16, 200, 80, 60), (3, 32, 60, 64, 64)])
+def test_odd_grids(dims):
+    check(S.make_scene("odd", dims=dims))
+
+
+def test_non_cubic_grid():
+    sc = S.make_scene("nc", dims=(6, 16, 300, 96, 64))
+    sc.N = (4, 6, 5)
+    check(sc)
+
+
+@pytest.mark.parametrize("border", [0, 2, 3])
+def test_border_sizes(border):
+    sc = S.make_scene("b", dims=(4, 16, 150, 96, 64), border=border)
+    check(sc)
+
+
+def test_nv64_extension():
+    """64^3-voxel bricks (beyond the reference's NUM_VOXELS 32 cap, Q21): two 32-slice register chunks."""
+    sc = S.make_scene("n64", dims=(3, 64, 40, 96, 64))
+    check(sc)
+
+
+def test_many_particles_in_one_metavoxel():
+    sc = S.make_scene("dense", dims=(4, 16, 700, 64, 48))
+    sc.particles["position"] *= 0.15                       # pile them up: several hundred per MV
+    o, g, _, _ = check(sc)
+    assert g.stats()["max_pairs_per_mv"] > 256
+
+
+def test_light_depth_map_and_scene_depth():
+    sc = S.make_scene("T0")
+    nv, N = sc.nv, sc.N[0]
+    rng = np.random.default_rng(3)
+    d = np.full((N * nv, N * nv), 1.0, dtype=np.float32)
+    d[: N * nv // 2] = (200.0 - 0.3 + rng.uniform(-3, 3, (N * nv // 2, N * nv))).astype(np.float32) / (1000.0 - 0.3)
+    sc.light_depth_map = d
+    sc.scene_depth = np.full((sc.height, sc.width), 1e9, dtype=np.float32)
+    sc.scene_depth[:, : sc.width // 2] = 10.0
+    o, g, io, ig = check(sc)
+    assert (ig[:, : sc.width // 3, 3].mean()) < ig[:, sc.width // 2 + 8:, 3].mean()
+
+
+def test_default_fast_mode_on_option_branches():
+    sc = S.make_scene("x", dims=(5, 32, 200, 96, 64), fade=1)
+    check(sc, exact=False)
+
+
+def test_call_order_and_argument_errors():
+    sc = S.make_scene("T0")
+    g = E.Engine(sc.config())
+    with pytest.raises(E.VpfxError) as ei:
+        g.bin(sc.particles, sc.layout, sc.psys_local_to_world)          # before set_frame
+    assert ei.value.code == abi.VP_ERR_STATE
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    with pytest.raises(E.VpfxError) as ei:
+        g.fill(sc.fill_params())                                        # before bin
+    assert ei.value.code == abi.VP_ERR_STATE
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    with pytest.raises(E.VpfxError) as ei:
+        g.raymarch(sc.camera(), sc.raymarch_params())                   # before fill
+    assert ei.value.code == abi.VP_ERR_STATE
+    fp = sc.fill_params()
+    fp.cubemap = None
+    with pytest.raises(E.VpfxError) as ei:
+        g.fill(fp)                                                      # no cubemap resident yet
+    assert ei.value.code == abi.VP_ERR_BAD_ARG
+    lay = S.particle_layout()
+    lay.off_size = 200                                                  # outside the 84-byte record
+    with pytest.raises(E.VpfxError) as ei:
+        g.bin(sc.particles, lay, sc.psys_local_to_world)
+    assert ei.value.code == abi.VP_ERR_BAD_ARG
+    with pytest.raises(E.VpfxError):
+        g.read_brick(0, 0, 0)                                           # not filled
+
+
+def test_refill_and_rebin_are_idempotent():
+    sc = S.make_scene("T0")
+    g = E.Engine(sc.config())
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    imgs = []
+    for _ in range(3):
+        g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        g.fill(sc.fill_params())
+        imgs.append(g.raymarch(sc.camera(), sc.raymarch_params()))
+    np.testing.assert_array_equal(imgs[0], imgs[1])
+    np.testing.assert_array_equal(imgs[0], imgs[2])
+
+
+def test_composite_kernel():
+    sc = S.make_scene("T0")
+    g = E.Engine(sc.config())
+    rng = np.random.default_rng(9)
+    a = rng.random((sc.height, sc.width, 1)).astype(np.float32)
+    p = np.concatenate([rng.random((sc.height, sc.width, 3)).astype(np.float32) * a, a], -1)
+    scene_rgba = rng.random((sc.height, sc.width, 4)).astype(np.float32)
+    dp, ds = torch.from_numpy(p).cuda(), torch.from_numpy(scene_rgba).cuda()
+    g.composite_device(dp.data_ptr(), ds.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ds.cpu().numpy(), O.composite(p, scene_rgba), atol=1e-6)
+
+
+def test_manager_mirrors_reference_frame_driver():
+    sc = S.make_scene("T0")
+    m = MetavoxelManager(sc.N[0], sc.N[1], sc.N[2], sc.mv_scale, sc.nv, sc.border, sc.width, sc.height)
+    m.Start()
+    m.SetLight(sc.light_to_world)
+    m.SetGridCenter(sc.grid_center)
+    m.SetDisplacementTexture(sc.cubemap)
+    m.updateInterval = 2
+    cam = sc.camera()
+    img0 = m.OnPostRender(0, sc.particles, sc.layout, cam).copy()      # frame 0: bin + fill + march
+    covered0 = m.numMetavoxelsCovered
+    moved = sc.particles.copy()
+    moved["position"] += 0.5
+    img1 = m.OnPostRender(1, moved, sc.layout, cam)                    # frame 1: march only (updateInterval gating, VPR.cs:186)
+    np.testing.assert_array_equal(img0, img1)
+    img2 = m.OnPostRender(2, moved, sc.layout, cam)                    # frame 2: refilled with the moved particles
+    assert np.abs(img2 - img0).max() > 1e-3
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    assert np.abs(o.raymarch(cam, sc.raymarch_params()) - img0).max() <= 1e-3
+    assert covered0 == o.stats()["occupied_mv"]
+    scene_rgba = np.full((sc.height, sc.width, 4), 0.25, dtype=np.float32)
+    m.OnPostRender(3, moved, sc.layout, cam, mainSceneRT=scene_rgba)
+    np.testing.assert_allclose(scene_rgba, O.composite(m.particlesRT, np.full_like(scene_rgba, 0.25)), atol=1e-6)
+
+
+def test_config2_full_parity():
+    """BASELINE config 2: 16^3 x 32^3, 10k particles, 1280x720 -- full per-pixel comparison."""
+    sc = S.make_scene("C2")
+    o, g = both(sc)
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ig).max() <= 1e-3
+    np.testing.assert_array_equal(o.bin_counts(), g.bin_counts())
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    assert g.stats()["samples"] <= o.stats()["samples"]               # saturation early-out skips exact no-ops only

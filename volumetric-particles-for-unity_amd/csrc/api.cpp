@@ -180,7 +180,7 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)))
         return fail(rc);
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 4; ++s)
         for (int j = 0; j < 2; ++j)
             if (hipEventCreate(&c->ev[s][j]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(VP_ERR_HIP); }
     *out = c;
@@ -196,7 +196,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_meta, c->d_bricks, c->d_dens_ao,
                    c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
-    for (int s = 0; s < 3; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
+    for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
     free(c->h_mvPos); free(c->h_rank);
     delete c;
 }
@@ -496,7 +496,7 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
 VP_EXPORT int vp_last_kernel_ms(vp_ctx* c, int32_t stage, float* ms)
 {
     if (!c) return VP_ERR_BAD_ARG;
-    if (!ms || stage < 0 || stage > 2) return vp_fail(c, VP_ERR_BAD_ARG, "vp_last_kernel_ms: bad argument");
+    if (!ms || stage < 0 || stage > 3) return vp_fail(c, VP_ERR_BAD_ARG, "vp_last_kernel_ms: bad argument");
     if (!c->ev_valid[stage]) return vp_fail(c, VP_ERR_STATE, "stage %d has not run", stage);
     int rc = ensure_device(c); if (rc) return rc;
     VP_HIP(hipEventSynchronize(c->ev[stage][1]));

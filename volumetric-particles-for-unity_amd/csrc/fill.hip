@@ -350,7 +350,8 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     P.light_in = d_light_in; P.light_out = d_light_out;
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao;
     const bool exact = c->cfg.reserved[0] == 1;      // cfg.reserved[0] = 1: IEEE divisions everywhere (parity builds)
-    VP_HIP(hipEventRecord(c->ev[1][0], c->stream));
+    const int evi = mode == 2 ? 3 : 1;
+    VP_HIP(hipEventRecord(c->ev[evi][0], c->stream));
     switch (c->g.nv) {
     case 16: launch_fill_nv<16>(c, mode, P, exact); break;
     case 32: launch_fill_nv<32>(c, mode, P, exact); break;
@@ -358,7 +359,7 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", c->g.nv);
     }
     VP_HIP(hipGetLastError());
-    VP_HIP(hipEventRecord(c->ev[1][1], c->stream));
-    c->ev_valid[1] = true;
+    VP_HIP(hipEventRecord(c->ev[evi][1], c->stream));
+    c->ev_valid[evi] = true;
     return VP_OK;
 }

@@ -128,8 +128,8 @@ struct vp_ctx {
     size_t brick_hit_cap = 0;
     long long last_samples = 0;
 
-    hipEvent_t ev[3][2]{};        // per stage start/stop of the dominant kernel
-    bool ev_valid[3] = {false, false, false};
+    hipEvent_t ev[4][2]{};        // start/stop of the dominant kernel per stage: 0 bin, 1 fill (fused or local), 2 raymarch, 3 fill_finish
+    bool ev_valid[4] = {false, false, false, false};
 
     std::string err;
 };
