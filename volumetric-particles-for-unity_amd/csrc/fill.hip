@@ -75,26 +75,33 @@ struct FillPtrs {
 template <bool EXACT>
 __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx, float psy, float psz, float& tx, float& ty)
 {
-    // D3D face selection, per-face bilinear, clamp.  Branch-free: the three major-axis cases differ only in which
-    // component feeds (sc, tc) and with which sign.
+    // D3D face selection, per-face bilinear, clamp.  Branch-free and written so that each select is one v_cndmask:
+    // the major axis is the component equal to max3(|x|,|y|,|z|) (ties: x before y before z, as the >= chain gives).
     const float ax = fabsf(psx), ay = fabsf(psy), az = fabsf(psz);
-    const bool xm = (ax >= ay) && (ax >= az);          // +-X face
-    const bool ym = !xm && (ay >= az);                 // +-Y face
+    const float ma = fmaxf(fmaxf(ax, ay), az);         // v_max3_f32
+    const bool xm = ax == ma;                          // ax >= ay && ax >= az : +-X face
+    const bool ym = !xm && (ay == ma);                 // else ay >= az        : +-Y face
     const bool px = psx >= 0.f, py = psy >= 0.f, pz = psz >= 0.f;
-    const float ma = xm ? ax : (ym ? ay : az);
     //      +X: sc=-z tc=-y | -X: sc=+z tc=-y | +Y: sc=+x tc=+z | -Y: sc=+x tc=-z | +Z: sc=+x tc=-y | -Z: sc=-x tc=-y
-    const float sc = xm ? (px ? -psz : psz) : (ym ? psx : (pz ? psx : -psx));
-    const float tc = ym ? (py ? psz : -psz) : -psy;
-    const bool pos = xm ? px : (ym ? py : pz);
+    const float sc_x = px ? -psz : psz;
+    const float sc_o = (ym || pz) ? psx : -psx;
+    const float sc = xm ? sc_x : sc_o;
+    const float tc_y = py ? psz : -psz;
+    const float tc = ym ? tc_y : -psy;
+    const bool pos = (xm && px) || (!xm && ((ym && py) || (!ym && pz)));
     const int S = f.cubeS, S1 = S + 1;
-    // row base of the face in the footprint table: (face * S1) with face = 2*axis + (pos ? 0 : 1)
+    // row base of the face in the footprint table: face * S1 with face = 2*axis + (pos ? 0 : 1)
     const int twoS1 = S1 + S1;
-    const int frow = (xm ? 0 : (ym ? twoS1 : twoS1 + twoS1)) + (pos ? 0 : S1);
+    const int fbase = xm ? 0 : (ym ? twoS1 : twoS1 + twoS1);
+    const int frow = fbase + (pos ? 0 : S1);
     float u = 0.f, v = 0.f;
     if (ma > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma); u = sc * inv; v = tc * inv; }
     const float fx = fmaf(u, f.half_s, f.half_s_m05), fy = fmaf(v, f.half_s, f.half_s_m05);
     const float x0 = floorf(fx), y0 = floorf(fy);
-    tx = fx - x0; ty = fy - y0;
+    // EXACT keeps the oracle's fx - floor(fx); the fast path uses v_fract_f32 (identical except that a weight that
+    // would round up to exactly 1.0 is returned as the largest float below 1)
+    tx = EXACT ? fx - x0 : __builtin_amdgcn_fractf(fx);
+    ty = EXACT ? fy - y0 : __builtin_amdgcn_fractf(fy);
     // |sc|, |tc| <= ma, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
     // the clamp-addressing of the footprint table never needs a min/max here (NaN converts to 0, also in range).
     const int ix = (int)x0 + 1, iy = (int)y0 + 1;                                             // [0, S]
