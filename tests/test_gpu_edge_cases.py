@@ -193,3 +193,32 @@ def test_config2_full_parity():
     np.testing.assert_array_equal(o.bin_counts(), g.bin_counts())
     np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
     assert g.stats()["samples"] <= o.stats()["samples"]               # saturation early-out skips exact no-ops only
+
+
+def test_config3_full_parity_and_properties():
+    """BASELINE config 3 (the benchmark workload) against the oracle on the GPU box's host cores, plus the
+    size-independent properties used for larger configs."""
+    sc = S.make_scene("C3")
+    g = E.Engine(sc.config(), early_out=False)
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    g.fill(sc.fill_params())
+    ig = g.raymarch(sc.camera(), sc.raymarch_params())
+    st = g.stats()
+    assert st["occupied_mv"] == 11325 and st["pairs"] == 480441 and st["max_pairs_per_mv"] == 83     # SURVEY App. C
+    lm = g.read_lightmap()
+    assert lm.min() >= 0.0 and lm.max() <= 1.0 and np.isfinite(ig).all()
+    assert ig[..., 3].min() >= 0.0 and ig[..., 3].max() <= 1.0 + 1e-6
+    # determinism: a second fill + march of the same inputs is bit-identical (sorted lists => fixed summation order)
+    g.fill(sc.fill_params())
+    np.testing.assert_array_equal(g.read_lightmap(), lm)
+    np.testing.assert_array_equal(g.raymarch(sc.camera(), sc.raymarch_params()), ig)
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    io = o.raymarch(sc.camera(), sc.raymarch_params())
+    np.testing.assert_array_equal(o.bin_counts(), g.bin_counts())
+    np.testing.assert_allclose(lm, o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    assert np.abs(io - ig).max() <= 1e-3
+    assert abs(o.stats()["samples"] - st["samples"]) <= 1e-5 * st["samples"]

@@ -90,7 +90,8 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     tEntry = max(tEntry, tCamera);                                                        // :240
     float rr = 0.f, rg = 0.f, rb = 0.f, trans = 1.0f;
     const float bx = ox + 0.5f, by = oy + 0.5f, bz = oz + 0.5f;
-    for (int si = tExit; si >= tEntry; --si) {                                            // back to front :254
+    // tex3D(_VolumeTexture, samplePos) at lattice index si                                :255-262
+    auto sample = [&](int si) -> F4 {
         const float t = (float)si * k.mvStep;
         // samplePos = (mvRayPos + 0.5)(1 - 2 bo) + bo, texel = samplePos*nv - 0.5        :255-258
         const float fx = fmaf(fmaf(t, R.dx, bx), k.texScale, k.texBias);
@@ -118,16 +119,26 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
             t01 = TexelPair{c0.x, c0.y, c1.x, c1.y}; t11 = TexelPair{d0.x, d0.y, d1.x, d1.y};
         }
         // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math),
-        // then y and z in f32.  tex3D :262
+        // then y and z in f32.
         const F4 c00 = lerp_x(t00, wx), c10 = lerp_x(t10, wx), c01 = lerp_x(t01, wx), c11 = lerp_x(t11, wx);
-        const F4 c = lerp4(lerp4(c00, c10, wy), lerp4(c01, c11, wy), wz);
+        return lerp4(lerp4(c00, c10, wy), lerp4(c01, c11, wy), wz);
+    };
+    auto blend = [&](const F4& c, int si) {
         float density = c.w;
         const int dc = si - tCamera;
         if (dc < k.soft) density *= (float)dc * k.inv_soft;                               // soft particles :267-270
         const float bf = __builtin_amdgcn_rcpf(1.0f + density);                           // :272
         rr = fmaf(bf, rr - c.x, c.x); rg = fmaf(bf, rg - c.y, c.y); rb = fmaf(bf, rb - c.z, c.z);   // lerp(color, result, bf) :274
         trans *= bf;                                                                      // :275
+    };
+    // back to front (:254), two lattice samples per iteration so that eight texel-pair loads are in flight
+    int si = tExit;
+    for (; si - 1 >= tEntry; si -= 2) {
+        const F4 c0 = sample(si), c1 = sample(si - 1);
+        blend(c0, si);
+        blend(c1, si - 1);
     }
+    if (si >= tEntry) blend(sample(si), si);
     nsamp += max(0, tExit - tEntry + 1);
     src = F4{rr, rg, rb, 1.0f - trans};                                                   // :301
     return true;
