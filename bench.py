@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--share-gpu", action="store_true", help="functional test only: all ranks on cuda:0")
+    ap.add_argument("--uniform-slabs", action="store_true", help="equal-thickness slabs instead of pair-count balanced ones")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,7 +89,29 @@ def main():
             dist.init_process_group(args.backend)
 
     sc = S.make_scene(args.config)
-    bounds = PAR.slab_bounds(sc.N[2], world)
+    weights = None
+    if world > 1 and not args.uniform_slabs:
+        # balanced slabs: every rank computes the same (particle, MV)-pair histogram along the light axis
+        probe = E.Engine(sc.config(device=local_rank))
+        probe.set_frame(sc.light_to_world, sc.grid_center)
+        probe.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+        weights = [float(x) for x in probe.z_histogram()]
+        probe.close()
+    bounds = PAR.slab_bounds(sc.N[2], world, weights)
+    # strong scaling: the unit of work is the SINGLE-GPU job (its voxels and its executed samples).  Sharded runs execute
+    # more lattice samples in total (the saturation early-out only sees one slab), which must not inflate `value`.
+    ref_units = None
+    if world > 1 and rank == 0:
+        one = E.Engine(sc.config(device=local_rank))
+        one.set_frame(sc.light_to_world, sc.grid_center)
+        one.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        one.fill(sc.fill_params())
+        one.raymarch_device(sc.camera(), sc.raymarch_params(), torch.empty((sc.height, sc.width, 4), device=device).data_ptr())
+        one.sync()
+        st1 = one.stats()
+        ref_units = (st1["voxels_filled"], st1["samples"])
+        one.close()
+        torch.cuda.empty_cache()
     eng = E.Engine(sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0)))
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
@@ -144,10 +167,22 @@ def main():
                          "unit": "GB/s", "bytes_per_launch": rm_bytes, "avg_ms": rm_ms,
                          "requested_GBps_64B_per_sample": st["samples"] * 64 / (rm_ms * 1e-3) / 1e9},
         }
-        for r in roofs.values():
+        # HBM traffic per launch measured with rocprofv3 PMC passes (scripts/gpu_prof2.sh -> profiles/*traffic*.json);
+        # bench.py cannot collect PMC counters itself, so the committed measurement of this same command is reported.
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        if world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath))
+        for name, r in roofs.items():
             r["frac"] = r["achieved"] / r["peak"]
-            r["traffic"] = None
+            t = traffic.get(r["kernel"])
+            r["traffic"] = t["traffic_bytes"] if t else None
+            if t:
+                r["traffic_source"] = f"profiles/traffic_{args.config}.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         dom = "fill" if fill_ms >= rm_ms else "raymarch"
+        executed = (voxels, samples)
+        if ref_units is not None:
+            voxels, samples = float(ref_units[0]), float(ref_units[1])
         out = {
             "metric": "Mvoxels/s filled + Msamples/s raymarched, 32^3x32^3 grid @1080p",
             "value": (voxels + samples) / (dt / args.steps) / 1e6,
@@ -159,7 +194,9 @@ def main():
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
                        "parallelism": f"zslab{world}", "slabs": bounds if world > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
-                       "samples_per_step": int(samples)},
+                       "samples_per_step": int(samples),
+                       "work_unit": "voxels + executed samples of the 1-GPU job (fixed for every N)",
+                       "samples_executed_all_ranks": int(executed[1])},
             "fill_mvoxels_per_s": voxels / (fill_ms * 1e-3) / 1e6 if world == 1 else None,
             "raymarch_msamples_per_s": samples / (rm_ms * 1e-3) / 1e6 if world == 1 else None,
             "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms,

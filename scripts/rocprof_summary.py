@@ -18,3 +18,5 @@ for db in sys.argv[1:]:
             print(f"{'kernel':40s} {'counter':24s} {'mean/dispatch':>18s} {'n':>4s} {'avg_ns':>12s} vgpr sgpr lds scratch")
             for n, cn, v, k, d, vg, sg, lds, sc in rows: print(f"{short(n):40s} {cn:24s} {v:18.1f} {k:4d} {d:12.0f} {vg} {sg} {lds} {sc}")
     except Exception as e: print("no counters:", e)
+
+# optional: --traffic-json OUT : HBM traffic per launch of the two dominant kernels from the FETCH_SIZE / WRITE_SIZE passes

@@ -96,3 +96,22 @@ def test_weighted_slab_bounds_cover_grid():
     b = PAR.slab_bounds(sc.N[2], 3, weights=[0, 10, 10, 0])
     assert b[0][0] == 0 and b[-1][1] == sc.N[2] and all(z1 > z0 for z0, z1 in b)
     assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+
+
+def test_z_histogram_matches_bin_counts_and_balances():
+    sc = S.make_scene("C1")
+    e = E.Engine(sc.config())
+    e.set_frame(sc.light_to_world, sc.grid_center)
+    e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+    h = e.z_histogram()
+    e.bin_resident()
+    np.testing.assert_array_equal(h, e.bin_counts().sum(axis=(1, 2)))
+    b = PAR.slab_bounds(sc.N[2], 4, [float(x) for x in h])
+    loads = [h[z0:z1].sum() for z0, z1 in b]
+    assert max(loads) <= 0.45 * h.sum()
+    out, lm, bounds, zb, straddler, _ = run_slabs(sc, 4, weights=[float(x) for x in h])
+    single = E.Engine(sc.config())
+    single.set_frame(sc.light_to_world, sc.grid_center)
+    single.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    single.fill(sc.fill_params())
+    assert np.abs(out - single.raymarch(sc.camera(), sc.raymarch_params())).max() <= 2e-5

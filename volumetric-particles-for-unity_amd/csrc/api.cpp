@@ -284,6 +284,26 @@ VP_EXPORT int vp_bin_resident(vp_ctx* c)
     return VP_OK;
 }
 
+VP_EXPORT int vp_z_histogram(vp_ctx* c, int64_t* pairs_per_z)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!pairs_per_z) return vp_fail(c, VP_ERR_BAD_ARG, "vp_z_histogram: null output");
+    if (!c->have_frame || !c->have_particles) return vp_fail(c, VP_ERR_STATE, "vp_z_histogram needs vp_set_frame and vp_upload_particles");
+    int rc = ensure_device(c); if (rc) return rc;
+    // d_cursor is free between bins (k_scan rewrites it); Nz <= N^3 ints
+    rc = launch_z_histogram(c, c->d_cursor); if (rc) return rc;
+    const int nz = c->g.Nz;
+    int* h = (int*)malloc((size_t)nz * sizeof(int));
+    if (!h) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
+    hipError_t e = hipMemcpyAsync(h, c->d_cursor, (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < nz; ++i) pairs_per_z[i] = h[i];
+    free(h);
+    if (e != hipSuccess) return vp_fail(c, VP_ERR_HIP, "vp_z_histogram: %s", hipGetErrorString(e));
+    c->binned = c->filled = c->local_done = false;        // the cursor scratch was reused
+    return VP_OK;
+}
+
 VP_EXPORT int vp_bin(vp_ctx* c, const void* particles, int32_t count, const vp_particle_layout* lay, const float psys_local_to_world[16])
 {
     int rc = vp_upload_particles(c, particles, count, lay, psys_local_to_world);

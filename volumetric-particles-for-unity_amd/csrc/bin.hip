@@ -86,7 +86,8 @@ k_extract(const uint8_t* __restrict__ raw, int P, vp_particle_layout lay, PsysCo
     dst[3] = make_float4(out[12], out[13], out[14], out[15]);
 }
 
-// One thread per particle.  MODE 0: count, MODE 1: scatter.                          VPR.cs:415-456
+// One thread per particle.  MODE 0: count, MODE 1: scatter, MODE 2: pairs per z-slice over the WHOLE grid
+// (load-balancing histogram for the multi-GPU slab split).                         VPR.cs:415-456
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restrict__ mvPos,
@@ -118,7 +119,7 @@ k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restri
     const int y0 = (int)fmaxf(0.f, piy - fe), y1 = (int)fminf((float)(g.Ny - 1), piy + fe);
     int z0 = (int)fmaxf(0.f, piz - fe), z1 = (int)fminf((float)(g.Nz - 1), piz + fe);
     // only the owned slab is binned (other slabs belong to other GPUs)
-    z0 = max(z0, g.z0); z1 = min(z1, g.z1 - 1);
+    if (MODE != 2) { z0 = max(z0, g.z0); z1 = min(z1, g.z1 - 1); }
     const float r = (w.w / 2.0f) / g.sb;                         // mvParticleRadius           :445
     for (int zz = z0; zz <= z1; ++zz)
         for (int yy = y0; yy <= y1; ++yy)
@@ -136,7 +137,8 @@ k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restri
                     else if (m > 0.5f) { const float d = m - 0.5f; r2 -= d * d; }
                 }
                 if (r2 > 0.f) {
-                    if (MODE == 0) atomicAdd(&count_or_cursor[mi], 1);
+                    if (MODE == 2) atomicAdd(&count_or_cursor[zz], 1);
+                    else if (MODE == 0) atomicAdd(&count_or_cursor[mi], 1);
                     else { const int slot = atomicAdd(&count_or_cursor[mi], 1); ids[offsets[mi] + slot] = p; }
                 }
             }
@@ -235,6 +237,17 @@ int launch_extract(vp_ctx* c)
     if (c->P == 0) return VP_OK;
     hipLaunchKernelGGL(k_extract, dim3((c->P + 255) / 256), dim3(256), 0, c->stream,
                        c->d_raw, c->P, c->lay, c->psys, c->d_ws, c->d_rec);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int launch_z_histogram(vp_ctx* c, int* d_hist)
+{
+    const GridConsts& g = c->g;
+    VP_HIP(hipMemsetAsync(d_hist, 0, (size_t)g.Nz * sizeof(int), c->stream));
+    if (c->P > 0)
+        hipLaunchKernelGGL(k_bin<2>, dim3((c->P + 255) / 256), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, d_hist,
+                           (const int*)nullptr, (int*)nullptr, c->d_rec);
     VP_HIP(hipGetLastError());
     return VP_OK;
 }

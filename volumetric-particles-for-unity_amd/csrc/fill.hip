@@ -88,12 +88,12 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     const float sc = xm ? sc_x : sc_o;
     const float tc_y = py ? psz : -psz;
     const float tc = ym ? tc_y : -psy;
-    const bool pos = (xm && px) || (!xm && ((ym && py) || (!ym && pz)));
     const int S = f.cubeS, S1 = S + 1;
-    // row base of the face in the footprint table: face * S1 with face = 2*axis + (pos ? 0 : 1)
+    // row base of the face in the footprint table: face * S1 with face = 2*axis + (major component < 0)
+    const float major = xm ? psx : (ym ? psy : psz);
     const int twoS1 = S1 + S1;
     const int fbase = xm ? 0 : (ym ? twoS1 : twoS1 + twoS1);
-    const int frow = fbase + (pos ? 0 : S1);
+    const int frow = fbase + ((major >= 0.f) ? 0 : S1);
     float u = 0.f, v = 0.f;
     if (ma > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma); u = sc * inv; v = tc * inv; }
     const float fx = fmaf(u, f.half_s, f.half_s_m05), fy = fmaf(v, f.half_s, f.half_s_m05);
@@ -110,10 +110,10 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
 }
 
 template <bool EXACT>
-__device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /* (t00, t10, t01, t11) */, float tx, float ty,
+__device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
                                            float d2, float opw, float& den, float& net)
 {
-    const float a = fmaf(tx, q.y - q.x, q.x), b = fmaf(tx, q.w - q.z, q.z);
+    const float a = fmaf(tx, q.z - q.x, q.x), b = fmaf(tx, q.w - q.y, q.y);
     const float raw = fmaf(ty, b - a, a);
     net = fmaf(f.D, raw, f.one_minus_D);                                          // netDisplacement   :119
     const float d2q = 4.0f * d2;                                                  // dot(2ps, 2ps)     :121
@@ -305,8 +305,9 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
     p_light_out[lmi] = prop;
 }
 
-// Expand the cubemap into bilinear footprints: quad(face, iy, ix) = texels (ix,iy),(ix+1,iy),(ix,iy+1),(ix+1,iy+1)
-// with clamp addressing, for ix, iy in [-1, S-1].
+// Expand the cubemap into bilinear footprints: quad(face, iy, ix) = texels (ix,iy),(ix,iy+1),(ix+1,iy),(ix+1,iy+1)
+// (the two x-neighbours of each row sit in registers q.x/q.z and q.y/q.w, so the x-lerp is one packed sub + one packed
+// fma on consecutive register pairs) with clamp addressing, for ix, iy in [-1, S-1].
 __global__ void __launch_bounds__(256)
 k_build_cubequads(const float* __restrict__ cube, int S, float4* __restrict__ quads)
 {
@@ -317,7 +318,7 @@ k_build_cubequads(const float* __restrict__ cube, int S, float4* __restrict__ qu
     const int x0 = min(max(ix, 0), S - 1), x1 = min(max(ix + 1, 0), S - 1);
     const int y0 = min(max(iy, 0), S - 1), y1 = min(max(iy + 1, 0), S - 1);
     const float* fc = cube + (size_t)face * S * S;
-    quads[i] = make_float4(fc[y0 * S + x0], fc[y0 * S + x1], fc[y1 * S + x0], fc[y1 * S + x1]);
+    quads[i] = make_float4(fc[y0 * S + x0], fc[y1 * S + x0], fc[y0 * S + x1], fc[y1 * S + x1]);
 }
 
 template <int NV>

@@ -172,8 +172,20 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, int early_out)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int col = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
+    // has its own L2.  Screen tiles are grouped into 4x2 super-tiles (64x32 px, about one brick's footprint); super-tile
+    // i is rendered entirely by XCD i % 8, so a brick is pulled into ~2-4 L2s instead of all eight, while neighbouring
+    // super-tiles still alternate XCDs (load balance across the image).
+    const int tgx = (k.W + 15) >> 4, tgy = (k.H + 15) >> 4;
+    const int sgx = (tgx + 3) >> 2, sgy = (tgy + 1) >> 1;
+    const int q = (int)(blockIdx.x >> 3);
+    const int sti = (q >> 3) * 8 + (int)(blockIdx.x & 7u);        // super-tile index
+    const int j = q & 7;                                          // tile inside the super-tile
+    if (sti >= sgx * sgy) return;
+    const int ttx = (sti % sgx) * 4 + (j & 3), tty = (sti / sgx) * 2 + (j >> 2);
+    if (ttx >= tgx || tty >= tgy) return;
+    const int col = ttx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int row = tty * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (col >= k.W || row >= k.H) return;
 
     // ray set-up                                                                          RM.shader:188-224
@@ -328,7 +340,8 @@ k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, si
 template <int NV>
 void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
 {
-    const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
+    const int nsuper = ((((k.W + 15) / 16) + 3) / 4) * ((((k.H + 15) / 16) + 1) / 2);
+    const dim3 grid(((nsuper + 7) / 8) * 64), block(256);
     const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
     if (d_under && wrap)
         hipLaunchKernelGGL((k_raymarch<NV, true, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,

@@ -110,7 +110,7 @@ struct vp_ctx {
     float2* d_dens_ao = nullptr;  // split-fill scratch [brick_cap][nv^3]
     size_t dens_cap = 0;
     float* d_lightmap = nullptr;  // [(Ny*nv)][(Nx*nv)]
-    float4* d_cubequads = nullptr;// [6][(S+1)][(S+1)] bilinear footprints
+    float4* d_cubequads = nullptr;// [6][(S+1)][(S+1)] bilinear footprints (t00, t01, t10, t11)
     int cubeS = 0;
     float* d_depthmap = nullptr;
     bool have_depthmap = false;
@@ -157,6 +157,7 @@ void   hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymar
 // bin.hip
 int  launch_extract(vp_ctx* c);
 int  launch_bin(vp_ctx* c);
+int  launch_z_histogram(vp_ctx* c, int* d_hist);
 // fill.hip
 int  launch_build_cubequads(vp_ctx* c, const float* d_cube, int S);
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish

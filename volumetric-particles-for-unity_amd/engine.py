@@ -163,6 +163,11 @@ class Engine:
     def composite_device(self, d_particles: int, d_scene: int):
         self._ck(self.L.vp_composite_device(self.h, C.c_void_p(d_particles), C.c_void_p(d_scene)), "vp_composite_device")
 
+    def z_histogram(self):
+        out = np.zeros(self.N[2], dtype=np.int64)
+        self._ck(self.L.vp_z_histogram(self.h, _vp(out)), "vp_z_histogram")
+        return out
+
     def z_boundary(self, cam):
         zb = C.c_int32(0)
         self._ck(self.L.vp_z_boundary(self.h, C.byref(cam), C.byref(zb)), "vp_z_boundary")
