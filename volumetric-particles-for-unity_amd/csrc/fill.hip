@@ -58,14 +58,15 @@ __device__ __forceinline__ float fdiv(float a, float b)
     const float* __restrict__ p_rec, const int* __restrict__ p_brick_index, const int* __restrict__ p_colorder, \
     const float4* __restrict__ p_cubequads, const float* __restrict__ p_depthmap /* nullable */,             \
     const float* __restrict__ p_light_in /* nullable => 1.0 */, float* __restrict__ p_light_out,             \
-    uint2* __restrict__ p_bricks, float2* __restrict__ p_dens_ao /* split-fill scratch */
+    uint2* __restrict__ p_bricks, float2* __restrict__ p_dens_ao /* split-fill scratch */,                         \
+    const float4* __restrict__ p_ws /* particle world position + diameter */
 #define FILL_PTR_ARGS(P) (P).mvPos, (P).offsets, (P).ids, (P).rec, (P).brick_index, (P).colorder, (P).cubequads, \
-                         (P).depthmap, (P).light_in, (P).light_out, (P).bricks, (P).dens_ao
+                         (P).depthmap, (P).light_in, (P).light_out, (P).bricks, (P).dens_ao, (P).ws
 
 struct FillPtrs {
     const float* mvPos; const int* offsets; const int* ids; const float* rec; const int* brick_index;
     const int* colorder; const float4* cubequads; const float* depthmap; const float* light_in;
-    float* light_out; uint2* bricks; float2* dens_ao;
+    float* light_out; uint2* bricks; float2* dens_ao; const float4* ws;
 };
 
 // compute_voxel_color (Fill.shader:110-135) for a covered voxel, split in two pipeline stages so that the one
@@ -126,7 +127,7 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
 // (propagation with T_in = 1) to light_out.
 template <int NV, bool EXACT, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)      // <= 128 VGPRs: 4 waves per SIMD
 k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
@@ -179,9 +180,35 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 #pragma unroll
             for (int s = 0; s < CH; ++s) { dens[s] = 0.f; ao[s] = 0.f; }                 // "clear it"  :178-181
 
+            // Vectorised pre-cull: 64 particles of the MV's list at a time, one per lane, sphere vs. this wave's
+            // 8x8-column x CH-slice box in voxel units (conservative); survivors are then taken in list order
+            // (ascending particle index = the reference's summation order) through the wave-uniform path below.
 #pragma unroll 1
-            for (int i = 0; i < n; ++i) {
-                const int pid = __builtin_amdgcn_readfirstlane(p_ids[off + i]);
+            for (int base = 0; base < n; base += 64) {
+            int pid_l = 0;
+            bool near = false;
+            if (base + lane < n) {
+                pid_l = p_ids[off + base + lane];
+                const float4 w = p_ws[pid_l];
+                const float dx = w.x - mvx, dy = w.y - mvy, dz = w.z - mvz;
+                const float sc_v = fnv * g.inv_sb;                                      // voxels per world unit
+                // voxel-index coordinates: column centres sit at px + 0.5, slices at s (no half-voxel offset in z, Q4)
+                const float cx = ((g.Rl[0] * dx + g.Rl[3] * dy) + g.Rl[6] * dz) * sc_v + 0.5f * fnv;
+                const float cy = ((g.Rl[1] * dx + g.Rl[4] * dy) + g.Rl[7] * dz) * sc_v + 0.5f * fnv;
+                const float cz = ((g.Rl[2] * dx + g.Rl[5] * dy) + g.Rl[8] * dz) * sc_v + 0.5f * fnv;
+                const float rv = 0.5f * w.w * sc_v * 1.002f + 0.05f;
+                const float bx0 = (float)(px - (lane & 7)) + 0.5f, by0 = (float)(py - (lane >> 3)) + 0.5f;
+                const float ex = fmaxf(fmaxf(bx0 - cx, cx - (bx0 + 7.0f)), 0.f);
+                const float ey = fmaxf(fmaxf(by0 - cy, cy - (by0 + 7.0f)), 0.f);
+                const float ez = fmaxf(fmaxf((float)c0 - cz, cz - (float)(c0 + CH - 1)), 0.f);
+                near = (ex * ex + ey * ey) + ez * ez <= rv * rv;
+            }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(near);
+#pragma unroll 1
+            while (todo) {
+                const int jl = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int pid = __builtin_amdgcn_readlane(pid_l, jl);
                 const float* r = p_rec + 16 * (size_t)pid;
                 const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
                 const float r8 = r[8], r9 = r[9], r10 = r[10], r11 = r[11];
@@ -225,6 +252,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                         ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
                     }
                 }
+            }
             }
 
             // propagate + store this chunk                                               Fill.shader:231-269
@@ -356,7 +384,7 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     P.brick_index = c->d_brick_index; P.colorder = c->d_colorder; P.cubequads = c->d_cubequads;
     P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
     P.light_in = d_light_in; P.light_out = d_light_out;
-    P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao;
+    P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
     const bool exact = c->cfg.reserved[0] == 1;      // cfg.reserved[0] = 1: IEEE divisions everywhere (parity builds)
     const int evi = mode == 2 ? 3 : 1;
     VP_HIP(hipEventRecord(c->ev[evi][0], c->stream));
