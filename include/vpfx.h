@@ -106,6 +106,17 @@ typedef struct vp_raymarch_params {
     int32_t reserved[4];
 } vp_raymarch_params;
 
+/* An opaque occluder: oriented box (the demo scene's ground/back planes and cubes are boxes).  Used to PRODUCE the two
+ * scene-occlusion inputs of the path on the GPU instead of reading them back from Unity render targets:
+ *   light depth map  <- lightCamera.RenderWithShader(GenerateLightDepthMap)   VPR.cs:184, 320-367, LDM.shader:6 (Cull Front:
+ *                        the nearest BACK face is what lands in the depth buffer)
+ *   eye scene depth  <- the main camera's depth buffer used by ZTest Less    VPR.cs:204, RM.shader:14 */
+typedef struct vp_obb {
+    float center[3];
+    float axes[9];                /* rows = the box's unit axes in world space                     */
+    float half_extent[3];
+} vp_obb;
+
 typedef struct vp_stats {
     int64_t particles;            /* particles uploaded                                           */
     int64_t occupied_mv;          /* numMetavoxelsCovered (VPR.cs:515), within the owned slab     */
@@ -157,6 +168,16 @@ int  vp_raymarch_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_par
 /* CompositeParticles.shader (Comp.shader:10, VPR.cs:210): scene.rgb = p.rgb + scene.rgb*(1-p.a),
  * scene.a += p.a; in place on device images [H][W][4] f32. */
 int  vp_composite_device(vp_ctx* ctx, const void* d_particles_rgba, void* d_scene_rgba);
+
+/* ---- scene occluders ---------------------------------------------------------- */
+/* Keep `n` occluder boxes in the context (n = 0 removes them).  While set, a vp_fill whose params carry no
+ * light_depth_map renders one from the boxes (ortho light camera of VPR.cs:320-367: extents = the grid's x/y size,
+ * position gridCenter - fwd * light_cam_distance, D3D depth (z - near)/(far - near)), and a vp_raymarch* whose params
+ * carry no scene_depth renders the eye depth (linear, nearest front face) from them. */
+int  vp_set_occluders(vp_ctx* ctx, const vp_obb* boxes, int32_t n);
+/* Parity probes: render and read back the two maps. */
+int  vp_render_light_depth(vp_ctx* ctx, float light_near, float light_far, float light_cam_distance, float* out /* [(Ny*nv)][(Nx*nv)] */);
+int  vp_render_scene_depth(vp_ctx* ctx, const vp_camera* cam, float* out /* [H][W] linear eye depth, 3e38 = nothing */);
 
 /* ---- multi-GPU (one context per GPU, each owning a contiguous zz slab) ---------------------- */
 /* Fill split at the only cross-slab dependency, the per-column transmitted light (Fill.shader:224,250):

@@ -160,6 +160,20 @@ class Oracle:
                  "vpo_raymarch_partial")
         return over, under, mask.value
 
+    def set_occluders(self, boxes):
+        arr = (type(boxes[0]) * len(boxes))(*boxes) if len(boxes) else None
+        self._ck(self.L.vpo_set_occluders(self.h, arr, len(boxes)), "vpo_set_occluders")
+
+    def render_light_depth(self, near=0.3, far=1000.0, cam_distance=200.0):
+        out = np.empty((self.N[1] * self.nv, self.N[0] * self.nv), dtype=np.float32)
+        self._ck(self.L.vpo_render_light_depth(self.h, C.c_float(near), C.c_float(far), C.c_float(cam_distance), _fp(out)), "vpo_render_light_depth")
+        return out
+
+    def render_scene_depth(self, cam):
+        out = np.empty((self.H, self.W), dtype=np.float32)
+        self._ck(self.L.vpo_render_scene_depth(self.h, C.byref(cam), _fp(out)), "vpo_render_scene_depth")
+        return out
+
     def z_boundary(self, cam):
         zb = C.c_int(0)
         self._ck(self.L.vpo_z_boundary(self.h, C.byref(cam), C.byref(zb)), "vpo_z_boundary")

@@ -197,6 +197,7 @@ typedef struct vpo_ctx {
     int filled;
     long samples;
     float* f16lut;               /* 65536 floats */
+    vp_obb* occluders; int n_occluders;
     char err[256];
 } vpo_ctx;
 
@@ -243,7 +244,7 @@ VPO_API void vpo_destroy(vpo_ctx* c)
     if (!c) return;
     free(c->mvPos); free(c->ws); free(c->psize); free(c->rec); free(c->offsets); free(c->ids);
     free(c->brick_index); free(c->bricks); free(c->dens_ao); free(c->cubemap); free(c->depthmap);
-    free(c->lightmap); free(c->f16lut); free(c);
+    free(c->lightmap); free(c->f16lut); free(c->occluders); free(c);
 }
 
 VPO_API int vpo_set_mode(vpo_ctx* c, int literal_stepping) { c->literal = literal_stepping; return VP_OK; }
@@ -488,6 +489,85 @@ static inline void voxel_color(const vpo_ctx* c, float psx, float psy, float psz
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Scene-occlusion inputs from occluder boxes.  Restates what Unity's rasteriser produces */
+/* for boxes: light depth map = nearest BACK face under the ortho light camera (LDM.shader:6 Cull Front,      */
+/* VPR.cs:184,320-367); eye depth = nearest front face of the main camera's opaque pass (VPR.cs:204).        */
+/* ------------------------------------------------------------------------------------------------ */
+static int ray_obb(const vp_obb* b, v3 o, v3 d, float* t0, float* t1)
+{
+    v3 p = v3_sub(o, v3_make(b->center[0], b->center[1], b->center[2]));
+    *t0 = -3.0e38f; *t1 = 3.0e38f;
+    for (int k = 0; k < 3; ++k) {
+        v3 a = v3_make(b->axes[3 * k], b->axes[3 * k + 1], b->axes[3 * k + 2]);
+        float lo = v3_dot(a, p), ld = v3_dot(a, d), h = b->half_extent[k];
+        if (ld != 0.f) {
+            float inv = 1.0f / ld;
+            float ta = (-h - lo) * inv, tb = (h - lo) * inv;
+            *t0 = fmaxf(*t0, fminf(ta, tb));
+            *t1 = fminf(*t1, fmaxf(ta, tb));
+        } else if (lo < -h || lo > h) return 0;
+    }
+    return *t0 <= *t1;
+}
+
+VPO_API int vpo_set_occluders(vpo_ctx* c, const vp_obb* boxes, int n)
+{
+    if (!c || n < 0 || (n > 0 && !boxes)) return VP_ERR_BAD_ARG;
+    free(c->occluders); c->occluders = NULL; c->n_occluders = n;
+    if (n > 0) { c->occluders = (vp_obb*)malloc((size_t)n * sizeof(vp_obb)); memcpy(c->occluders, boxes, (size_t)n * sizeof(vp_obb)); }
+    return VP_OK;
+}
+
+VPO_API int vpo_render_light_depth(vpo_ctx* c, float nearz, float farz, float cam_dist, float* out)
+{
+    if (!c || !out || !c->have_frame) return VP_ERR_STATE;
+    const int LW = c->Nx * c->nv, LH = c->Ny * c->nv;
+    /* Ortho(-r, r, -t, t, 0.3, 1000), r = Nx*s/2, t = Ny*s/2                                 VPR.cs:338-342 */
+    const float r = (float)c->Nx * c->s * 0.5f, t = (float)c->Ny * c->s * 0.5f;
+    const float cx = c->gc[0] - c->fwd.x * cam_dist, cy = c->gc[1] - c->fwd.y * cam_dist, cz = c->gc[2] - c->fwd.z * cam_dist;   /* :365 */
+    for (int Y = 0; Y < LH; ++Y)
+        for (int X = 0; X < LW; ++X) {
+            const float lx = -r + ((float)X + 0.5f) / (float)LW * (2.0f * r);
+            const float ly = -t + ((float)Y + 0.5f) / (float)LH * (2.0f * t);
+            v3 o = v3_make(cx + c->Rl[0] * lx + c->Rl[1] * ly, cy + c->Rl[3] * lx + c->Rl[4] * ly, cz + c->Rl[6] * lx + c->Rl[7] * ly);
+            float zmin = 3.0e38f;
+            for (int i = 0; i < c->n_occluders; ++i) {
+                float t0, t1;
+                if (!ray_obb(&c->occluders[i], o, c->fwd, &t0, &t1)) continue;
+                if (t1 >= nearz && t1 <= farz) zmin = fminf(zmin, t1);           /* Cull Front: the back face is drawn */
+            }
+            out[(size_t)Y * LW + X] = zmin < 3.0e38f ? (zmin - nearz) / (farz - nearz) : 1.0f;
+        }
+    return VP_OK;
+}
+
+VPO_API int vpo_render_scene_depth(vpo_ctx* c, const vp_camera* cam, float* out)
+{
+    if (!c || !cam || !out) return VP_ERR_BAD_ARG;
+    const int W = c->W, H = c->H;
+    const float aspect = (float)W / (float)H;
+    const float nit = -(1.0f / (float)tan((double)cam->fov_y * 0.5));
+    const float* m = cam->camera_to_world;
+    const float farc = cam->far_clip > 0.f ? cam->far_clip : 3.0e38f;
+    v3 o = v3_make(M(m, 0, 3), M(m, 1, 3), M(m, 2, 3));
+    for (int row = 0; row < H; ++row)
+        for (int col = 0; col < W; ++col) {
+            v3 d = v3_make((2.0f * ((float)col + 0.5f) / (float)W - 1.0f) * aspect, 2.0f * ((float)row + 0.5f) / (float)H - 1.0f, nit);
+            v3 w = mul_dir(m, d);
+            float best = 3.0e38f;
+            for (int i = 0; i < c->n_occluders; ++i) {
+                float t0, t1;
+                if (!ray_obb(&c->occluders[i], o, w, &t0, &t1)) continue;
+                float te = t0 > 0.f ? t0 : t1;
+                float depth = te * (-nit);
+                if (te > 0.f && depth >= cam->near_clip && depth <= farc) best = fminf(best, depth);
+            }
+            out[(size_t)row * W + col] = best;
+        }
+    return VP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* F5-F12: FillMetavoxels / FillMetavoxel / frag                   VPR.cs:495-609, Fill.shader:152-274 */
 /* ------------------------------------------------------------------------------------------------ */
 static int retain_fill_params(vpo_ctx* c, const vp_fill_params* p)
@@ -503,6 +583,10 @@ static int retain_fill_params(vpo_ctx* c, const vp_fill_params* p)
         size_t dn = (size_t)c->Nx * c->nv * c->Ny * c->nv;
         c->depthmap = (float*)malloc(dn * sizeof(float));
         memcpy(c->depthmap, p->light_depth_map, dn * sizeof(float));
+    } else if (c->n_occluders > 0) {
+        size_t dn = (size_t)c->Nx * c->nv * c->Ny * c->nv;
+        c->depthmap = (float*)malloc(dn * sizeof(float));
+        vpo_render_light_depth(c, p->light_near, p->light_far, p->light_cam_distance, c->depthmap);
     }
     c->fp.cubemap = NULL; c->fp.light_depth_map = NULL;
     return VP_OK;
@@ -942,6 +1026,13 @@ static int raymarch_impl(vpo_ctx* c, const vp_camera* cam, const vp_raymarch_par
     if (!c->filled) { snprintf(c->err, sizeof c->err, "raymarch before fill"); return VP_ERR_STATE; }
     if (rp->steps_per_mv < 1 || c->W < 1 || c->H < 1) return VP_ERR_BAD_ARG;
     rm_consts k; make_rm_consts(c, cam, rp, &k);
+    float* occ_depth = NULL;
+    const float* scene_depth = rp->scene_depth;
+    if (!scene_depth && c->n_occluders > 0) {
+        occ_depth = (float*)malloc((size_t)c->W * c->H * sizeof(float));
+        vpo_render_scene_depth(c, cam, occ_depth);
+        scene_depth = occ_depth;
+    }
     int *order, *kind;
     int n = build_draw_order(c, cam, &order, &kind);
     const size_t nv3 = (size_t)c->nv * c->nv * c->nv;
@@ -977,7 +1068,7 @@ static int raymarch_impl(vpo_ctx* c, const vp_camera* cam, const vp_raymarch_par
             for (int row = ya; row <= yb; ++row)
                 for (int col = rc[0]; col <= rc[2]; ++col) {
                     v3 dir, start; ray_setup(&k, col, row, &dir, &start);
-                    float sd = rp->scene_depth ? rp->scene_depth[(size_t)row * c->W + col] : 3.0e38f;
+                    float sd = scene_depth ? scene_depth[(size_t)row * c->W + col] : 3.0e38f;
                     float src[4]; int ns;
                     if (!march_mv(c, &k, cm, brick, dir, start, sd, src, &ns)) continue;
                     total_samples += ns;
@@ -993,7 +1084,7 @@ static int raymarch_impl(vpo_ctx* c, const vp_camera* cam, const vp_raymarch_par
         }
     }
     c->samples = total_samples;
-    free(order); free(kind); free(c2m); free(rects);
+    free(order); free(kind); free(c2m); free(rects); free(occ_depth);
     return VP_OK;
 }
 

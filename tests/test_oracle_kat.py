@@ -175,3 +175,49 @@ def test_scene_depth_rejects_metavoxels_behind_geometry():
     np.testing.assert_array_equal(none, 0.0)
     sc.scene_depth = np.full((sc.height, sc.width), 1e6, dtype=np.float32)
     np.testing.assert_array_equal(o.raymarch(sc.camera(), sc.raymarch_params()), full)
+
+
+def _light_axes(sc):
+    L = np.asarray(sc.light_to_world, dtype=np.float64).reshape(4, 4).T
+    return L[:3, :3]
+
+
+def test_occluder_box_light_depth_is_nearest_back_face():
+    """GenerateLightDepthMap.shader renders with Cull Front: the depth that lands in the map is the box's BACK face."""
+    sc = S.make_scene("T0")
+    o = engine(sc)
+    R = _light_axes(sc)
+    fwd = R[:, 2]
+    box = S.make_box(center=fwd * 3.0 + R[:, 0] * 3.0, half_extent=(3.0, 20.0, 0.25), rot3=R.T)
+    o.set_occluders([box])
+    d = o.render_light_depth()
+    expect = (200.0 + 3.0 + 0.25 - 0.3) / (1000.0 - 0.3)
+    W = d.shape[1]
+    np.testing.assert_allclose(d[:, W // 2:], expect, rtol=2e-6)         # light-space x in [0, 6]: covered
+    np.testing.assert_array_equal(d[:, : W // 2], 1.0)                     # cleared depth elsewhere
+    # two boxes: ZTest Less keeps the nearer back face
+    box2 = S.make_box(center=fwd * -2.0, half_extent=(1.0, 1.0, 0.5), rot3=R.T)
+    o.set_occluders([box, box2])
+    d2 = o.render_light_depth()
+    assert d2.min() == pytest.approx((200.0 - 2.0 + 0.5 - 0.3) / 999.7, rel=2e-6)
+    # and the fill consumes it: same result as passing the rendered map explicitly
+    o.fill(sc.fill_params())
+    lm = o.read_lightmap()
+    sc.light_depth_map = d2
+    o2 = engine(sc)
+    o2.fill(sc.fill_params())
+    np.testing.assert_array_equal(lm, o2.read_lightmap())
+
+
+def test_occluder_box_scene_depth_is_nearest_front_face():
+    sc = S.make_scene("T0")
+    o = engine(sc)
+    cam_pos = np.asarray(sc.cam_pos, dtype=np.float64)
+    fwd = -np.asarray(sc.cam_to_world)[:3, 2]
+    c2w = np.asarray(sc.cam_to_world)
+    box = S.make_box(center=cam_pos + fwd * 1.5, half_extent=(100.0, 100.0, 0.5), rot3=c2w[:3, :3].T)   # wall facing the camera
+    o.set_occluders([box])
+    sd = o.render_scene_depth(sc.camera())
+    np.testing.assert_allclose(sd, 1.0, rtol=1e-5)                          # linear eye depth of the front face
+    o.fill(sc.fill_params())
+    np.testing.assert_array_equal(o.raymarch(sc.camera(), sc.raymarch_params()), 0.0)   # everything is behind the wall

@@ -94,6 +94,11 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
         VP_HIP(hipMemcpyAsync(c->d_depthmap, p->light_depth_map, lightmap_elems(c) * sizeof(float), hipMemcpyHostToDevice, c->stream));
         VP_HIP(hipStreamSynchronize(c->stream));
         c->have_depthmap = true;
+    } else if (c->n_occluders > 0) {
+        // no map given but occluder boxes are set: render the light depth map on the GPU (VPR.cs:184)
+        if (!c->d_depthmap) { int rc = dev_alloc(c, &c->d_depthmap, lightmap_elems(c)); if (rc) return rc; }
+        int rc = launch_light_depth(c, p->light_near, p->light_far, p->light_cam_distance, c->d_depthmap); if (rc) return rc;
+        c->have_depthmap = true;
     } else {
         c->have_depthmap = false;                               // NULL = no occluders (depth 1.0 everywhere)
     }
@@ -120,6 +125,10 @@ int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp
         if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
         VP_HIP(hipMemcpyAsync(c->d_scene_depth, rp->scene_depth, (size_t)c->cfg.width * c->cfg.height * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
+    } else if (c->n_occluders > 0) {
+        // no depth buffer given but occluder boxes are set: render the eye depth on the GPU (VPR.cs:204)
+        if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
+        int rc = launch_scene_depth(c, cam, c->d_scene_depth); if (rc) return rc;
     }
     // h_rank / scene_depth are pageable: the async copies above have already consumed them on return
     return VP_OK;
@@ -178,7 +187,8 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, &c->d_brick_index, c->n3)) || (rc = dev_alloc(c, &c->d_occ_list, c->n3)) ||
         (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
-        (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)))
+        (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
+        (rc = dev_alloc(c, &c->d_cam_rows, 12)))
         return fail(rc);
     for (int s = 0; s < 4; ++s)
         for (int j = 0; j < 2; ++j)
@@ -194,7 +204,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_meta, c->d_bricks, c->d_dens_ao,
-                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_image, c->d_scene_depth, c->d_samples};
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
     free(c->h_mvPos); free(c->h_rank);
@@ -351,9 +361,8 @@ VP_EXPORT int vp_raymarch_device(vp_ctx* c, const vp_camera* cam, const vp_rayma
     int rc = ensure_device(c); if (rc) return rc;
     RmConsts k;
     rc = stage_raymarch(c, cam, rp, &k); if (rc) return rc;
-    if (!rp->scene_depth) { /* no occluders */ }
     float* keep = c->d_scene_depth;
-    if (!rp->scene_depth) c->d_scene_depth = nullptr;
+    if (!rp->scene_depth && c->n_occluders == 0) c->d_scene_depth = nullptr;
     rc = launch_raymarch(c, k, (float*)d_rgba_out, nullptr);
     c->d_scene_depth = keep;
     return rc;
@@ -383,7 +392,7 @@ VP_EXPORT int vp_raymarch_partial_device(vp_ctx* c, const vp_camera* cam, const 
         *phase_mask = (k.z0 <= k.zB ? 1 : 0) | (k.z1 - 1 > k.zB ? 2 : 0);
     }
     float* keep = c->d_scene_depth;
-    if (!rp->scene_depth) c->d_scene_depth = nullptr;
+    if (!rp->scene_depth && c->n_occluders == 0) c->d_scene_depth = nullptr;
     rc = launch_raymarch(c, k, (float*)d_over, (float*)d_under);
     c->d_scene_depth = keep;
     return rc;
@@ -411,6 +420,62 @@ VP_EXPORT int vp_z_boundary(vp_ctx* c, const vp_camera* cam, int32_t* zb)
     if (!cam || !zb) return vp_fail(c, VP_ERR_BAD_ARG, "vp_z_boundary: null argument");
     if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_z_boundary before vp_set_frame");
     *zb = hl_z_boundary(c, cam);
+    return VP_OK;
+}
+
+// ---- scene occluders -----------------------------------------------------------------------------------
+VP_EXPORT int vp_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (n < 0 || (n > 0 && !boxes)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders: bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    if (n > c->occluders_cap) {
+        if (c->d_occluders) VP_HIP(hipFree(c->d_occluders));
+        c->d_occluders = nullptr; c->occluders_cap = 0;
+        VP_HIP(hipMalloc((void**)&c->d_occluders, (size_t)(n + 8) * sizeof(vp_obb)));
+        c->occluders_cap = n + 8;
+    }
+    if (n > 0) {
+        VP_HIP(hipMemcpyAsync(c->d_occluders, boxes, (size_t)n * sizeof(vp_obb), hipMemcpyHostToDevice, c->stream));
+        VP_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->n_occluders = n;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_render_light_depth(vp_ctx* c, float light_near, float light_far, float light_cam_distance, float* out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!out || !(light_far > light_near)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_render_light_depth: bad argument");
+    if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_render_light_depth before vp_set_frame");
+    int rc = ensure_device(c); if (rc) return rc;
+    float* d_tmp = nullptr;
+    VP_HIP(hipMalloc((void**)&d_tmp, lightmap_elems(c) * sizeof(float)));
+    rc = launch_light_depth(c, light_near, light_far, light_cam_distance, d_tmp);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(out, d_tmp, lightmap_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_tmp);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return vp_fail(c, VP_ERR_HIP, "vp_render_light_depth: copy failed");
+    return VP_OK;
+}
+
+VP_EXPORT int vp_render_scene_depth(vp_ctx* c, const vp_camera* cam, float* out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!cam || !out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_render_scene_depth: null argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    const size_t n = (size_t)c->cfg.width * c->cfg.height;
+    float* d_tmp = nullptr;
+    VP_HIP(hipMalloc((void**)&d_tmp, n * sizeof(float)));
+    rc = launch_scene_depth(c, cam, d_tmp);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(out, d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_tmp);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return vp_fail(c, VP_ERR_HIP, "vp_render_scene_depth: copy failed");
     return VP_OK;
 }
 

@@ -116,6 +116,11 @@ struct vp_ctx {
     bool have_depthmap = false;
     FillConsts fc{};
 
+    // occluder boxes (scene-occlusion inputs produced on the GPU)
+    vp_obb* d_occluders = nullptr;
+    int n_occluders = 0, occluders_cap = 0;
+    float* d_cam_rows = nullptr;  // 12 floats
+
     // raymarch
     float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
     size_t mvtrans_cap = 0;
@@ -165,3 +170,6 @@ int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_ou
 int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under);
 int  launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out);
 int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);
+// occluders.hip
+int  launch_light_depth(vp_ctx* c, float nearz, float farz, float cam_dist, float* d_out);
+int  launch_scene_depth(vp_ctx* c, const vp_camera* cam, float* d_out);

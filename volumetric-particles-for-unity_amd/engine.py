@@ -163,6 +163,20 @@ class Engine:
     def composite_device(self, d_particles: int, d_scene: int):
         self._ck(self.L.vp_composite_device(self.h, C.c_void_p(d_particles), C.c_void_p(d_scene)), "vp_composite_device")
 
+    def set_occluders(self, boxes):
+        arr = (abi.vp_obb * len(boxes))(*boxes) if len(boxes) else None
+        self._ck(self.L.vp_set_occluders(self.h, arr, len(boxes)), "vp_set_occluders")
+
+    def render_light_depth(self, near=0.3, far=1000.0, cam_distance=200.0):
+        out = np.empty((self.N[1] * self.nv, self.N[0] * self.nv), dtype=np.float32)
+        self._ck(self.L.vp_render_light_depth(self.h, C.c_float(near), C.c_float(far), C.c_float(cam_distance), _vp(out)), "vp_render_light_depth")
+        return out
+
+    def render_scene_depth(self, cam):
+        out = np.empty((self.H, self.W), dtype=np.float32)
+        self._ck(self.L.vp_render_scene_depth(self.h, C.byref(cam), _vp(out)), "vp_render_scene_depth")
+        return out
+
     def z_histogram(self):
         out = np.zeros(self.N[2], dtype=np.int64)
         self._ck(self.L.vp_z_histogram(self.h, _vp(out)), "vp_z_histogram")

@@ -221,3 +221,15 @@ def make_scene(name: str = "C1", *, seed: int = 1234, size_range=(0.6, 1.4), rot
     D = 0.8 * N * s
     sc.set_camera((-0.125 * D, 0.05 * D, -D))
     return sc
+
+
+def make_box(center, half_extent, rot3=None) -> abi.vp_obb:
+    """Oriented occluder box (rows of `rot3` = the box's unit axes in world space; default axis-aligned)."""
+    b = abi.vp_obb()
+    r = np.eye(3) if rot3 is None else np.asarray(rot3, dtype=np.float64)
+    for i in range(3):
+        b.center[i] = float(center[i])
+        b.half_extent[i] = float(half_extent[i])
+    for i in range(9):
+        b.axes[i] = float(r.reshape(9)[i])
+    return b
