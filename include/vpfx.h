@@ -56,7 +56,9 @@ typedef struct vp_config {
     int32_t width, height;    /* Screen.width / height (particlesRT extent)            VPR.cs:228 */
     int32_t device;           /* HIP device ordinal, -1 = current device                          */
     int32_t slab_z0, slab_z1; /* owned light-axis slab zz in [z0,z1); 0,0 = whole grid (1 GPU)    */
-    int32_t reserved[5];
+    int32_t exact_math;       /* 1: IEEE divisions in the fill kernel (bit-parity test builds)     */
+    int32_t no_early_out;     /* 1: the ray-march never stops early (sample-count parity tests)    */
+    int32_t reserved[3];
 } vp_config;
 
 /* Byte layout of one caller-side particle record (ParticleSystem.Particle[], VPR.cs:412-413).
@@ -103,8 +105,15 @@ typedef struct vp_raymarch_params {
     int32_t soft_distance;        /* softParticleStepDistance (_SoftDistance)                     */
     const float* scene_depth;     /* optional [H][W] f32 linear eye depth of opaque scene for the
                                      ZTest Less rejection (RM.shader:14); NULL = no occluders     */
-    int32_t reserved[4];
+    int32_t flags;                /* VP_RM_* bits                                                  */
+    int32_t reserved[3];
 } vp_raymarch_params;
+
+/* vp_raymarch_params.flags */
+#define VP_RM_QUANTIZE_UNORM8  1  /* emulate the reference's 8-bit particlesRT (ARGB32, VPR.cs:228): the render target is
+                                     re-quantised to UNORM8 after every metavoxel blend.  Default: fp32 */
+#define VP_RM_SHOW_NUM_SAMPLES 2  /* _ShowNumSamples debug view: colour-code the samples taken per metavoxel (RM.shader:283-299) */
+#define VP_RM_SHOW_BLEND_FUNC  4  /* _ShowRayMarchBlendFunc debug view: yellow = OVER, cyan = UNDER (RM.shader:174-181)        */
 
 /* An opaque occluder: oriented box (the demo scene's ground/back planes and cubes are boxes).  Used to PRODUCE the two
  * scene-occlusion inputs of the path on the GPU instead of reading them back from Unity render targets:

@@ -901,7 +901,7 @@ typedef struct {
     v3 csVolOrigin;
     float maxDim, halfZ, zMin, rayLen, mvStep;
     float nearc, farc;
-    int steps, soft;
+    int steps, soft, flags;
     float bo;
 } rm_consts;
 
@@ -969,6 +969,12 @@ static int march_mv(const vpo_ctx* c, const rm_consts* k, const float* c2m, cons
         (*nsamp)++;
     }
     src[0] = res[0]; src[1] = res[1]; src[2] = res[2]; src[3] = 1.0f - trans;          /* :301 */
+    if (k->flags & VP_RM_SHOW_NUM_SAMPLES) {                                           /* debug view :283-299 */
+        static const float tab[7][4] = {{0.f, 0.2f, 0.f, 0.5f}, {0.f, 0.5f, 0.f, 0.5f}, {0.5f, 0.5f, 0.f, 0.5f}, {0.6f, 0.4f, 0.f, 0.5f},
+                                        {0.6f, 0.f, 0.f, 0.5f}, {0.8f, 0.f, 0.f, 0.5f}, {1.0f, 0.f, 0.f, 0.5f}};
+        int n = *nsamp, i = n < 5 ? 0 : n < 10 ? 1 : n < 20 ? 2 : n < 30 ? 3 : n < 40 ? 4 : n < 50 ? 5 : 6;
+        memcpy(src, tab[i], sizeof tab[i]);
+    }
     return 1;
 }
 
@@ -988,7 +994,7 @@ static void make_rm_consts(const vpo_ctx* c, const vp_camera* cam, const vp_raym
     float mvRayLength = k->rayLen * (1.0f / c->s);                   /* :222 */
     k->mvStep = mvRayLength * invTotal;                              /* :223 */
     k->nearc = cam->near_clip; k->farc = cam->far_clip > 0.f ? cam->far_clip : 3.0e38f;
-    k->steps = rp->steps_per_mv; k->soft = rp->soft_distance;
+    k->steps = rp->steps_per_mv; k->soft = rp->soft_distance; k->flags = rp->flags;
     k->bo = (1.0f / (float)c->nv) * (float)c->b;                     /* rcp(_NumVoxels)*_MetavoxelBorderSize :245 */
 }
 
@@ -1072,6 +1078,10 @@ static int raymarch_impl(vpo_ctx* c, const vp_camera* cam, const vp_raymarch_par
                     float src[4]; int ns;
                     if (!march_mv(c, &k, cm, brick, dir, start, sd, src, &ns)) continue;
                     total_samples += ns;
+                    if (k.flags & VP_RM_SHOW_BLEND_FUNC) {                     /* debug view          RM.shader:174-181 */
+                        if (kind[i] == 0) { src[0] = 0.5f; src[1] = 0.5f; src[2] = 0.f; src[3] = 1.f; }
+                        else { src[0] = 0.f; src[1] = 0.5f; src[2] = 0.5f; src[3] = 1.f; }
+                    }
                     float* dst = img + ((size_t)row * c->W + col) * 4;
                     if (kind[i] == 0) {        /* Blend One OneMinusSrcAlpha (all channels)      VPR.cs:659-662 */
                         float ia = 1.0f - src[3];
@@ -1080,6 +1090,8 @@ static int raymarch_impl(vpo_ctx* c, const vp_camera* cam, const vp_raymarch_par
                         float ia = 1.0f - dst[3];
                         for (int ch = 0; ch < 4; ++ch) dst[ch] = src[ch] * ia + dst[ch];
                     }
+                    if (k.flags & VP_RM_QUANTIZE_UNORM8)                       /* particlesRT is ARGB32 (Q19)   VPR.cs:228 */
+                        for (int ch = 0; ch < 4; ++ch) dst[ch] = floorf(fminf(fmaxf(dst[ch], 0.f), 1.f) * 255.0f + 0.5f) / 255.0f;
                 }
         }
     }

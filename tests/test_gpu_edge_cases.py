@@ -259,3 +259,26 @@ def E_free_alpha(sc):
     g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     g.fill(sc.fill_params())
     return g.raymarch(sc.camera(), sc.raymarch_params())[..., 3].mean()
+
+
+@pytest.mark.parametrize("flag,tol", [(abi.VP_RM_QUANTIZE_UNORM8, 1.01 / 255), (abi.VP_RM_SHOW_NUM_SAMPLES, 1e-6), (abi.VP_RM_SHOW_BLEND_FUNC, 1e-6),
+                                      (abi.VP_RM_QUANTIZE_UNORM8 | abi.VP_RM_SHOW_NUM_SAMPLES, 1.01 / 255)])
+def test_render_target_emulation_and_debug_views(flag, tol):
+    """8-bit particlesRT emulation (quirk Q19) and the two shader debug views, GPU vs oracle."""
+    sc = S.make_scene("T0")
+    sc.set_camera((1.5, 14.0, 1.0))                      # OVER and UNDER phases both present
+    o, g = both(sc, early_out=False)
+    rp = sc.raymarch_params()
+    rp.flags = flag
+    io, ig = o.raymarch(sc.camera(), rp), g.raymarch(sc.camera(), rp)
+    d = np.abs(io - ig)
+    if flag & abi.VP_RM_QUANTIZE_UNORM8:
+        # both are on the 1/255 lattice; a blend landing within float noise of a rounding boundary may differ by one step
+        np.testing.assert_allclose(io * 255, np.rint(io * 255), atol=1e-3)
+        np.testing.assert_allclose(ig * 255, np.rint(ig * 255), atol=1e-3)
+        assert d.max() <= tol and (d > 1e-6).mean() < 2e-3
+    else:
+        assert d.max() <= tol
+    if flag == abi.VP_RM_SHOW_BLEND_FUNC:
+        cols = {tuple(np.round(c, 3)) for c in ig.reshape(-1, 4)[::7]}
+        assert (0.0, 0.0, 0.0, 0.0) in cols and len(cols) >= 2

@@ -221,3 +221,17 @@ def test_occluder_box_scene_depth_is_nearest_front_face():
     np.testing.assert_allclose(sd, 1.0, rtol=1e-5)                          # linear eye depth of the front face
     o.fill(sc.fill_params())
     np.testing.assert_array_equal(o.raymarch(sc.camera(), sc.raymarch_params()), 0.0)   # everything is behind the wall
+
+
+def test_unorm8_emulation_quantises_every_blend():
+    from vpfx_amd import abi
+    sc = S.make_scene("T0")
+    o = engine(sc)
+    o.fill(sc.fill_params())
+    rp = sc.raymarch_params()
+    ref = o.raymarch(sc.camera(), rp)
+    rp.flags = abi.VP_RM_QUANTIZE_UNORM8
+    q = o.raymarch(sc.camera(), rp)
+    np.testing.assert_allclose(q * 255, np.rint(q * 255), atol=1e-3)        # on the UNORM8 lattice
+    assert 1e-4 < np.abs(q - ref).max() < 0.1                                # differs from fp32 blending, but not wildly (Q19)
+    assert o.stats()["samples"] > 0

@@ -13,6 +13,10 @@ VP_ERR_STATE = -4
 VP_ERR_NO_DEVICE = -5
 VP_ERR_UNSUPPORTED = -6
 
+VP_RM_QUANTIZE_UNORM8 = 1
+VP_RM_SHOW_NUM_SAMPLES = 2
+VP_RM_SHOW_BLEND_FUNC = 4
+
 STATUS_NAMES = {
     0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
     -4: "VP_ERR_STATE", -5: "VP_ERR_NO_DEVICE", -6: "VP_ERR_UNSUPPORTED",
@@ -32,7 +36,9 @@ class vp_config(C.Structure):
         ("device", C.c_int32),
         ("slab_z0", C.c_int32),
         ("slab_z1", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("exact_math", C.c_int32),
+        ("no_early_out", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -82,7 +88,8 @@ class vp_raymarch_params(C.Structure):
         ("steps_per_mv", C.c_int32),
         ("soft_distance", C.c_int32),
         ("scene_depth", c_float_p),
-        ("reserved", C.c_int32 * 4),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

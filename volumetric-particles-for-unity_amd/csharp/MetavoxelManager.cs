@@ -42,8 +42,8 @@ namespace MetavoxelEngine
         struct vp_config
         {
             public int nx, ny, nz, num_voxels, num_border; public float mv_scale;
-            public int width, height, device, slab_z0, slab_z1;
-            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 5)] public int[] reserved;
+            public int width, height, device, slab_z0, slab_z1, exact_math, no_early_out;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public int[] reserved;
         }
         [StructLayout(LayoutKind.Sequential)]
         struct vp_particle_layout
@@ -69,7 +69,8 @@ namespace MetavoxelEngine
         struct vp_raymarch_params
         {
             public int steps_per_mv, soft_distance; public IntPtr scene_depth;
-            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 4)] public int[] reserved;
+            public int flags;      // VP_RM_* bits (1 = UNORM8 render-target emulation, 2 / 4 = debug views)
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public int[] reserved;
         }
 
         const string LIB = "vpfx";
@@ -108,7 +109,7 @@ namespace MetavoxelEngine
             var cfg = new vp_config {
                 nx = numMetavoxelsX, ny = numMetavoxelsY, nz = numMetavoxelsZ, num_voxels = numVoxelsInMetavoxel,
                 num_border = numBorderVoxels, mv_scale = mvScale.x, width = Screen.width, height = Screen.height,
-                device = -1, slab_z0 = 0, slab_z1 = 0, reserved = new int[5] };
+                device = -1, slab_z0 = 0, slab_z1 = 0, exact_math = 0, no_early_out = 0, reserved = new int[3] };
             int rc = vp_create(ref cfg, out ctx);
             if (rc != 0) { Debug.LogError("vp_create failed (" + rc + "): " + Marshal.PtrToStringAnsi(vp_last_error(IntPtr.Zero))); return; }
             parts = new ParticleSystem.Particle[particleSys.maxParticles];
@@ -193,7 +194,7 @@ namespace MetavoxelEngine
                 world_to_camera = ToArray(c.worldToCameraMatrix), camera_to_world = ToArray(c.cameraToWorldMatrix),
                 px = cp.x, py = cp.y, pz = cp.z, fov_y = Mathf.Deg2Rad * c.fieldOfView, near_clip = c.nearClipPlane, far_clip = c.farClipPlane };
             var rp = new vp_raymarch_params { steps_per_mv = rayMarchSteps, soft_distance = softParticleStepDistance,
-                                              scene_depth = IntPtr.Zero, reserved = new int[4] };
+                                              scene_depth = IntPtr.Zero, flags = 0, reserved = new int[3] };
             GCHandle h = GCHandle.Alloc(rgba, GCHandleType.Pinned);
             try { Check(vp_raymarch(ctx, ref cam, ref rp, h.AddrOfPinnedObject()), "vp_raymarch"); }
             finally { h.Free(); }

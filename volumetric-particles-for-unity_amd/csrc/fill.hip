@@ -385,7 +385,7 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
     P.light_in = d_light_in; P.light_out = d_light_out;
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
-    const bool exact = c->cfg.reserved[0] == 1;      // cfg.reserved[0] = 1: IEEE divisions everywhere (parity builds)
+    const bool exact = c->cfg.exact_math == 1;        // IEEE divisions everywhere (parity builds)
     const int evi = mode == 2 ? 3 : 1;
     VP_HIP(hipEventRecord(c->ev[evi][0], c->stream));
     switch (c->g.nv) {

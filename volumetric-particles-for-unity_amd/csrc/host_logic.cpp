@@ -154,6 +154,7 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
     k->Nx = g.Nx; k->Ny = g.Ny; k->Nz = g.Nz; k->nv = g.nv; k->z0 = g.z0; k->z1 = g.z1;
     k->zB = hl_z_boundary(c, cam);
     k->steps = rp->steps_per_mv; k->soft = rp->soft_distance;
+    k->flags = rp->flags;
     k->aspect = (float)k->W / (float)k->H;                                   // RM.shader:190
     k->neg_inv_tan = -(1.0f / (float)std::tan((double)cam->fov_y * 0.5));    // RM.shader:193
     const float* w2c = cam->world_to_camera;

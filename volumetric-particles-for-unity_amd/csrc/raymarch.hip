@@ -51,6 +51,9 @@ __device__ __forceinline__ F4 lerp_x(const TexelPair t, float w)
     return F4{mix_lerp_lo(w, t.rg0, t.rg1), mix_lerp_hi(w, t.rg0, t.rg1), mix_lerp_lo(w, t.ba0, t.ba1), mix_lerp_hi(w, t.ba0, t.ba1)};
 }
 
+// D3D11 float -> UNORM8 -> float round trip: clamp, scale, round to nearest
+__device__ __forceinline__ float unorm8(float x) { return floorf(fminf(fmaxf(x, 0.f), 1.f) * 255.0f + 0.5f) / 255.0f; }
+
 struct RayCtx {
     float ogx, ogy, ogz;      // ray origin (csAABBStart) in grid space               (traversal only)
     float dgx, dgy, dgz;      // normalised direction in grid space                     (traversal only)
@@ -139,8 +142,14 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
         blend(c1, si - 1);
     }
     if (si >= tEntry) blend(sample(si), si);
-    nsamp += max(0, tExit - tEntry + 1);
+    const int ns = max(0, tExit - tEntry + 1);
+    nsamp += ns;
     src = F4{rr, rg, rb, 1.0f - trans};                                                   // :301
+    if (k.flags & VP_RM_SHOW_NUM_SAMPLES) {                                               // debug view :283-299
+        src = ns < 5 ? F4{0.f, 0.2f, 0.f, 0.5f} : ns < 10 ? F4{0.f, 0.5f, 0.f, 0.5f} : ns < 20 ? F4{0.5f, 0.5f, 0.f, 0.5f}
+            : ns < 30 ? F4{0.6f, 0.4f, 0.f, 0.5f} : ns < 40 ? F4{0.6f, 0.f, 0.f, 0.5f} : ns < 50 ? F4{0.8f, 0.f, 0.f, 0.5f}
+            : F4{1.0f, 0.f, 0.f, 0.5f};
+    }
     return true;
 }
 
@@ -285,6 +294,8 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             const int ns0 = nsamp;
             if (!march_mv<NV, WRAP>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
+            if (k.flags & VP_RM_SHOW_BLEND_FUNC)            // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
+                src = over ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
             if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
                 const float ia = 1.0f - src.w;
                 dstA.x = src.x + dstA.x * ia; dstA.y = src.y + dstA.y * ia; dstA.z = src.z + dstA.z * ia; dstA.w = src.w + dstA.w * ia;
@@ -292,6 +303,10 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
                 F4& d = PARTIAL ? dstB : dstA;
                 const float ia = 1.0f - d.w;
                 d.x = src.x * ia + d.x; d.y = src.y * ia + d.y; d.z = src.z * ia + d.z; d.w = src.w * ia + d.w;
+            }
+            if (k.flags & VP_RM_QUANTIZE_UNORM8) {          // particlesRT is ARGB32: the ROP stores UNORM8 (Q19)    VPR.cs:228
+                F4& d = (PARTIAL && !over) ? dstB : dstA;
+                d.x = unorm8(d.x); d.y = unorm8(d.y); d.z = unorm8(d.z); d.w = unorm8(d.w);
             }
         }
         if (!over && early_out) {
@@ -361,7 +376,7 @@ void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, i
 
 int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
 {
-    const int early_out = c->cfg.reserved[1] == 1 ? 0 : 1;     // cfg.reserved[1] = 1 disables the saturation early-out
+    const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC))) ? 0 : 1;
     VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
     const int nocc = c->h_meta.occupied;
     if ((size_t)nocc > c->mvtrans_cap) {

@@ -47,6 +47,7 @@ struct FillConsts {
 struct RmConsts {
     int W, H, Nx, Ny, Nz, nv, z0, z1;
     int zB, steps, soft, partial;
+    int flags, pad1, pad2, pad3;  // VP_RM_* bits of vp_raymarch_params.flags
     float aspect, neg_inv_tan, zMin, s;
     float mvStep, inv_mvStep, nearc, farc;
     float c2m_lin[9];             // linear part of _CameraToMetavoxel (identical for every MV), rows     VPR.cs:778

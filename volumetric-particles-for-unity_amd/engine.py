@@ -52,8 +52,8 @@ class Engine:
         self.L = lib()
         self.h = C.c_void_p()
         cfg = _copy_cfg(cfg)
-        cfg.reserved[0] = 1 if exact else 0          # IEEE divisions in the fill kernel (bit-parity builds)
-        cfg.reserved[1] = 0 if early_out else 1      # saturation early-out of the ray-march
+        cfg.exact_math = 1 if exact else 0           # IEEE divisions in the fill kernel (bit-parity builds)
+        cfg.no_early_out = 0 if early_out else 1     # saturation early-out of the ray-march
         self.cfg = cfg
         rc = self.L.vp_create(C.byref(cfg), C.byref(self.h))
         if rc:
