@@ -70,7 +70,7 @@ struct RayCtx {
 // expressed in THIS metavoxel's unit-cube space through _CameraToMetavoxel (mv translation column `tr`), so
 // tEntry / tExit / tCamera are bit-identical to the per-draw values.  Returns false when the rasteriser would
 // not have produced a fragment (or the shader's own box test misses); src is premultiplied (rgb, 1 - T).
-template <int NV, bool WRAP>
+template <int NV, bool WRAP, bool FLAGS>
 __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, const uint2* __restrict__ brick, const float4 tr,
                                          F4& src, int& nsamp)
 {
@@ -145,7 +145,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     const int ns = max(0, tExit - tEntry + 1);
     nsamp += ns;
     src = F4{rr, rg, rb, 1.0f - trans};                                                   // :301
-    if (k.flags & VP_RM_SHOW_NUM_SAMPLES) {                                               // debug view :283-299
+    if (FLAGS && (k.flags & VP_RM_SHOW_NUM_SAMPLES)) {                                    // debug view :283-299
         src = ns < 5 ? F4{0.f, 0.2f, 0.f, 0.5f} : ns < 10 ? F4{0.f, 0.5f, 0.f, 0.5f} : ns < 20 ? F4{0.5f, 0.5f, 0.f, 0.5f}
             : ns < 30 ? F4{0.6f, 0.4f, 0.f, 0.5f} : ns < 40 ? F4{0.6f, 0.f, 0.f, 0.5f} : ns < 50 ? F4{0.8f, 0.f, 0.f, 0.5f}
             : F4{1.0f, 0.f, 0.f, 0.5f};
@@ -174,7 +174,8 @@ k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict
 
 // PARTIAL = false: the reference's single render target.  PARTIAL = true: OVER-phase and UNDER-phase MVs of the
 // owned slab composite into two separate images (multi-GPU partial images).
-template <int NV, bool PARTIAL, bool WRAP>
+// FLAGS = false compiles the vp_raymarch_params.flags paths (UNORM8 emulation, debug views) out of the hot loop.
+template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
 __global__ void __launch_bounds__(256)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
@@ -292,9 +293,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             const int bi = occ[best_cell];
             F4 src;
             const int ns0 = nsamp;
-            if (!march_mv<NV, WRAP>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+            if (!march_mv<NV, WRAP, FLAGS>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
-            if (k.flags & VP_RM_SHOW_BLEND_FUNC)            // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
+            if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
                 src = over ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
             if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
                 const float ia = 1.0f - src.w;
@@ -304,7 +305,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
                 const float ia = 1.0f - d.w;
                 d.x = src.x * ia + d.x; d.y = src.y * ia + d.y; d.z = src.z * ia + d.z; d.w = src.w * ia + d.w;
             }
-            if (k.flags & VP_RM_QUANTIZE_UNORM8) {          // particlesRT is ARGB32: the ROP stores UNORM8 (Q19)    VPR.cs:228
+            if (FLAGS && (k.flags & VP_RM_QUANTIZE_UNORM8)) {   // particlesRT is ARGB32: the ROP stores UNORM8 (Q19)    VPR.cs:228
                 F4& d = (PARTIAL && !over) ? dstB : dstA;
                 d.x = unorm8(d.x); d.y = unorm8(d.y); d.z = unorm8(d.z); d.w = unorm8(d.w);
             }
@@ -352,24 +353,30 @@ k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, si
     scene[i] = d;
 }
 
-template <int NV>
-void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
+template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
+void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
 {
     const int nsuper = ((((k.W + 15) / 16) + 3) / 4) * ((((k.H + 15) / 16) + 1) / 2);
     const dim3 grid(((nsuper + 7) / 8) * 64), block(256);
+    hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
+                       c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
+}
+
+template <int NV>
+void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
+{
     const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
-    if (d_under && wrap)
-        hipLaunchKernelGGL((k_raymarch<NV, true, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
-                           c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
-    else if (wrap)
-        hipLaunchKernelGGL((k_raymarch<NV, false, true>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
-                           c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, c->d_brick_hit, early_out);
-    else if (d_under)
-        hipLaunchKernelGGL((k_raymarch<NV, true, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
-                           c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
-    else
-        hipLaunchKernelGGL((k_raymarch<NV, false, false>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans, c->d_rank,
-                           c->d_scene_depth, (float4*)d_over, (float4*)nullptr, c->d_samples, c->d_brick_hit, early_out);
+    const int sel = (d_under ? 4 : 0) | (wrap ? 2 : 0) | (k.flags ? 1 : 0);
+    switch (sel) {
+    case 0: launch_rm_variant<NV, false, false, false>(c, k, d_over, d_under, early_out); break;
+    case 1: launch_rm_variant<NV, false, false, true>(c, k, d_over, d_under, early_out); break;
+    case 2: launch_rm_variant<NV, false, true, false>(c, k, d_over, d_under, early_out); break;
+    case 3: launch_rm_variant<NV, false, true, true>(c, k, d_over, d_under, early_out); break;
+    case 4: launch_rm_variant<NV, true, false, false>(c, k, d_over, d_under, early_out); break;
+    case 5: launch_rm_variant<NV, true, false, true>(c, k, d_over, d_under, early_out); break;
+    case 6: launch_rm_variant<NV, true, true, false>(c, k, d_over, d_under, early_out); break;
+    default: launch_rm_variant<NV, true, true, true>(c, k, d_over, d_under, early_out); break;
+    }
 }
 
 }  // namespace
