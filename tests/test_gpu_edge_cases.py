@@ -282,3 +282,36 @@ def test_render_target_emulation_and_debug_views(flag, tol):
     if flag == abi.VP_RM_SHOW_BLEND_FUNC:
         cols = {tuple(np.round(c, 3)) for c in ig.reshape(-1, 4)[::7]}
         assert (0.0, 0.0, 0.0, 0.0) in cols and len(cols) >= 2
+
+
+def test_demo_scene_sequence_with_emitter_and_occluders():
+    """The reference's own scene (10^3 x 32^3 grid, emitter parameters, camera, light, ground/back/cubes) driven frame by
+    frame through MetavoxelManager.OnPostRender; the frame after each refill is checked against the oracle."""
+    sc, em, boxes = S.make_demo_scene(width=256, height=192)
+    m = MetavoxelManager(10, 10, 10, 3.0, 32, 1, sc.width, sc.height)
+    m.Start()
+    m.SetLight(sc.light_to_world)
+    m.SetGridCenter(sc.grid_center)
+    m.psysLocalToWorld = sc.psys_local_to_world
+    m.SetDisplacementTexture(sc.cubemap)
+    m.SetOccluders(boxes)
+    cam = sc.camera()
+    checked = 0
+    for frame in range(6):
+        em.step(1.0 / 30.0)
+        parts = em.particles()
+        assert 50 <= len(parts) <= 60
+        img = m.OnPostRender(frame, parts, sc.layout, cam)
+        if frame % m.updateInterval == 0 and frame in (0, 4):
+            o = O.Oracle(sc.config())
+            o.set_frame(sc.light_to_world, sc.grid_center)
+            o.set_occluders(boxes)
+            o.bin(parts, sc.layout, sc.psys_local_to_world)
+            o.fill(sc.fill_params())
+            ref = o.raymarch(cam, sc.raymarch_params())
+            assert m.numMetavoxelsCovered == o.stats()["occupied_mv"] > 0
+            bad = (np.abs(ref - img).max(axis=-1) > 1e-3).sum()
+            assert bad <= 3, bad
+            assert img[..., 3].max() > 0.05
+            checked += 1
+    assert checked == 2

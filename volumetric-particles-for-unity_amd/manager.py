@@ -128,6 +128,11 @@ class MetavoxelManager:
         self.wsGridCenter = np.ascontiguousarray(pos, dtype=np.float32)
         self._frame_dirty = True                                                # gridCenter moved: VPR.cs:189
 
+    def SetOccluders(self, boxes):
+        """Opaque scene geometry as boxes: the light depth map and the eye depth are then rendered on the GPU
+        (what lightCamera.RenderWithShader and the main camera's depth buffer provide in the reference, VPR.cs:184,204)."""
+        self._engine.set_occluders(list(boxes))
+
     def SetDisplacementTexture(self, cubemap):
         self.displacementCubemap = cubemap
         self._cubemap_dirty = True

@@ -233,3 +233,84 @@ def make_box(center, half_extent, rot3=None) -> abi.vp_obb:
     for i in range(9):
         b.axes[i] = float(r.reshape(9)[i])
     return b
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The demo scene of the reference (Assets/Volumetric_Particle_System.unity) -- SURVEY section 8(f) row 3
+# ---------------------------------------------------------------------------------------------------------------
+class DemoEmitter:
+    """A deterministic stand-in for the demo's Unity ParticleSystem ("Particle System Demo", scene:2264-2620):
+    cone shape (angle 10 deg, radius 0.5), 10 particles/s, lifetime 6 s, speed 3, size 4, random start rotation,
+    angular velocity 0.0698 rad/s, at most `max_particles` (scene: 60, slider 0-128), simulated in LOCAL space.
+    Unity's own emitter/RNG is closed source, so this reproduces the documented parameters, not its random stream.
+    `particles()` returns the live particles in the ParticleSystem.Particle layout the C ABI consumes."""
+
+    def __init__(self, seed=7, rate=10.0, lifetime=6.0, speed=3.0, size=4.0, cone_deg=10.0, radius=0.5,
+                 ang_vel_deg=4.0, max_particles=60):
+        self.rng = np.random.default_rng(seed)
+        self.rate, self.lifetime, self.speed, self.size = rate, lifetime, speed, size
+        self.cone, self.radius, self.ang_vel, self.max = math.radians(cone_deg), radius, ang_vel_deg, max_particles
+        self.t, self.acc = 0.0, 0.0
+        self.pos = np.zeros((0, 3)); self.vel = np.zeros((0, 3)); self.rot = np.zeros(0); self.life = np.zeros(0)
+
+    def step(self, dt):
+        self.t += dt
+        self.pos = self.pos + self.vel * dt
+        self.rot = self.rot + self.ang_vel * dt
+        self.life = self.life - dt
+        keep = self.life > 0
+        self.pos, self.vel, self.rot, self.life = self.pos[keep], self.vel[keep], self.rot[keep], self.life[keep]
+        self.acc += self.rate * dt
+        n = min(int(self.acc), self.max - len(self.life))
+        self.acc -= int(self.acc)
+        if n > 0:
+            r = self.radius * np.sqrt(self.rng.random(n))
+            phi = self.rng.uniform(0, 2 * math.pi, n)
+            base = np.stack([r * np.cos(phi), r * np.sin(phi), np.zeros(n)], -1)
+            tilt = self.cone * (r / self.radius)                      # edge of the base emits along the cone surface
+            d = np.stack([np.sin(tilt) * np.cos(phi), np.sin(tilt) * np.sin(phi), np.cos(tilt)], -1)
+            self.pos = np.concatenate([self.pos, base])
+            self.vel = np.concatenate([self.vel, d * self.speed])
+            self.rot = np.concatenate([self.rot, self.rng.uniform(0, 360, n)])
+            self.life = np.concatenate([self.life, np.full(n, self.lifetime)])
+
+    def particles(self):
+        p = np.zeros(len(self.life), dtype=PARTICLE_DTYPE)
+        p["position"] = self.pos.astype(np.float32)
+        p["velocity"] = self.vel.astype(np.float32)
+        p["size"] = self.size
+        p["rotation"] = np.mod(self.rot, 360.0).astype(np.float32)    # degrees (the C# property)
+        p["lifetime"] = self.life.astype(np.float32)
+        p["startLifetime"] = self.lifetime
+        p["axisOfRotation"] = (0.0, 0.0, 1.0)
+        p["color"] = 0xFFFFFFFF
+        return p
+
+
+def make_demo_scene(width=1024, height=768, warm_seconds=6.0, seed=7):
+    """The reference's scene: 10^3 metavoxels x 32^3 voxels of size 3 (scene:9013-9016), main camera at (-10,0,-20) looking
+    +z with fov 60, directional light quaternion (0.1856,0,0,0.9826), grid centre at world (0,-5,0), particle system at world
+    (0,0,11.2) rotated 180 deg about Y, ground / back planes and two cubes as occluder boxes.  Returns (scene, emitter, boxes)."""
+    em = DemoEmitter(seed=seed)
+    steps = int(round(warm_seconds * 30))
+    for _ in range(steps):
+        em.step(1.0 / 30.0)
+    parts = em.particles()
+    light = trs((0.0, 0.0, -44.34), quat_to_matrix((0.185593992, 0.0, 0.0, 0.982626557)))
+    psys = trs((0.0, 0.0, 11.2), quat_to_matrix((0.0, 1.0, 0.0, -4.37113883e-08)))
+    sc = Scene(name="DEMO", N=(10, 10, 10), nv=32, border=1, mv_scale=3.0, width=width, height=height, particles=parts,
+               layout=particle_layout(False), psys_local_to_world=to_colmajor16(psys), light_to_world=to_colmajor16(light),
+               grid_center=np.array([0.0, -5.0, 0.0], dtype=np.float32), cubemap=make_cubemap(), light_depth_map=None,
+               scene_depth=None)
+    c2w = np.eye(4)
+    c2w[:3, 2] = (0.0, 0.0, -1.0)                   # Unity camera looks down its +z; view space looks down -z
+    c2w[:3, 3] = (-10.0, 0.0, -20.0)
+    sc.cam_to_world, sc.world_to_cam = c2w, np.linalg.inv(c2w)
+    sc.cam_pos = np.array([-10.0, 0.0, -20.0], dtype=np.float32)
+    boxes = [
+        make_box((0.0, -6.52 - 0.05, 0.0), (250.0, 0.05, 250.0)),                    # ground plane (10x10 mesh, scale 50)
+        make_box((0.0, 19.0, 24.5 + 0.05), (250.0, 250.0, 0.05)),                    # back wall (plane rotated 90 deg about x)
+        make_box((-5.34, 1.18, -11.89), (0.5, 0.5, 0.5)),                            # Cube
+        make_box((0.0, -0.43, -11.0), (0.5, 0.5, 0.5)),                              # Cube 1
+    ]
+    return sc, em, boxes
