@@ -106,9 +106,9 @@ class Twin:
         S = cube.shape[1]
         x, y, z = d[..., 0], d[..., 1], d[..., 2]
         ax, ay, az = np.abs(x), np.abs(y), np.abs(z)
-        isx = (ax >= ay) & (ax >= az)
-        isy = ~isx & (ay >= az)
-        isz = ~isx & ~isy
+        isz = (az >= ax) & (az >= ay)              # ties: z before y before x (GCN cube instructions; D3D leaves it open)
+        isy = ~isz & (ay >= ax)
+        isx = ~isz & ~isy
         ma = np.where(isx, ax, np.where(isy, ay, az))
         face = np.where(isx, np.where(x >= 0, 0, 1), np.where(isy, np.where(y >= 0, 2, 3), np.where(z >= 0, 4, 5)))
         sc_ = np.where(isx, np.where(x >= 0, -z, z), np.where(isy, x, np.where(z >= 0, x, -x)))

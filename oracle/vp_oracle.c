@@ -453,9 +453,11 @@ static float sample_cubemap(const float* cube, int S, float dx, float dy, float 
 {
     float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
     int face; float ma, sc, tc;
-    if (ax >= ay && ax >= az) { ma = ax; if (dx >= 0.f) { face = 0; sc = -dz; tc = -dy; } else { face = 1; sc = dz; tc = -dy; } }
-    else if (ay >= az)        { ma = ay; if (dy >= 0.f) { face = 2; sc = dx; tc = dz; } else { face = 3; sc = dx; tc = -dz; } }
-    else                      { ma = az; if (dz >= 0.f) { face = 4; sc = dx; tc = -dy; } else { face = 5; sc = -dx; tc = -dy; } }
+    /* major axis: D3D leaves ties implementation-defined; the spec resolves them as the GCN/CDNA cube
+     * instructions do (z before y before x), probed on gfx950 (scripts/probes/cube_probe.hip). */
+    if (az >= ax && az >= ay) { ma = az; if (dz >= 0.f) { face = 4; sc = dx; tc = -dy; } else { face = 5; sc = -dx; tc = -dy; } }
+    else if (ay >= ax)        { ma = ay; if (dy >= 0.f) { face = 2; sc = dx; tc = dz; } else { face = 3; sc = dx; tc = -dz; } }
+    else                      { ma = ax; if (dx >= 0.f) { face = 0; sc = -dz; tc = -dy; } else { face = 1; sc = dz; tc = -dy; } }
     float u, v;
     if (ma > 0.f) { float inv = 1.0f / ma; u = sc * inv; v = tc * inv; } else { u = 0.f; v = 0.f; }
     float hs = 0.5f * (float)S;

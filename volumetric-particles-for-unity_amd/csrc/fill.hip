@@ -76,38 +76,28 @@ struct FillPtrs {
 template <bool EXACT>
 __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx, float psy, float psz, float& tx, float& ty)
 {
-    // D3D face selection, per-face bilinear, clamp.  Branch-free and written so that each select is one v_cndmask:
-    // the major axis is the component equal to max3(|x|,|y|,|z|) (ties: x before y before z, as the >= chain gives).
-    const float ax = fabsf(psx), ay = fabsf(psy), az = fabsf(psz);
-    const float ma = fmaxf(fmaxf(ax, ay), az);         // v_max3_f32
-    const bool xm = ax == ma;                          // ax >= ay && ax >= az : +-X face
-    const bool ym = !xm && (ay == ma);                 // else ay >= az        : +-Y face
-    const bool px = psx >= 0.f, py = psy >= 0.f, pz = psz >= 0.f;
-    //      +X: sc=-z tc=-y | -X: sc=+z tc=-y | +Y: sc=+x tc=+z | -Y: sc=+x tc=-z | +Z: sc=+x tc=-y | -Z: sc=-x tc=-y
-    const float sc_x = px ? -psz : psz;
-    const float sc_o = (ym || pz) ? psx : -psx;
-    const float sc = xm ? sc_x : sc_o;
-    const float tc_y = py ? psz : -psz;
-    const float tc = ym ? tc_y : -psy;
-    const int S = f.cubeS, S1 = S + 1;
-    // row base of the face in the footprint table: face * S1 with face = 2*axis + (major component < 0)
-    const float major = xm ? psx : (ym ? psy : psz);
-    const int twoS1 = S1 + S1;
-    const int fbase = xm ? 0 : (ym ? twoS1 : twoS1 + twoS1);
-    const int frow = fbase + ((major >= 0.f) ? 0 : S1);
-    float u = 0.f, v = 0.f;
-    if (ma > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma); u = sc * inv; v = tc * inv; }
-    const float fx = fmaf(u, f.half_s, f.half_s_m05), fy = fmaf(v, f.half_s, f.half_s_m05);
+    // D3D cube-face selection with the CDNA cube-map VALU instructions (v_cubeid/sc/tc/ma_f32): face id, the two in-face
+    // coordinates and 2x the signed major component in four instructions instead of ~25 compares and selects.  Ties
+    // between |x|, |y|, |z| resolve z before y before x -- the arithmetic spec adopts exactly that rule.
+    const float fid = __builtin_amdgcn_cubeid(psx, psy, psz);          // 0..5 = +X,-X,+Y,-Y,+Z,-Z
+    const float sc = __builtin_amdgcn_cubesc(psx, psy, psz);
+    const float tc = __builtin_amdgcn_cubetc(psx, psy, psz);
+    const float ma2 = fabsf(__builtin_amdgcn_cubema(psx, psy, psz));   // 2 |major|
+    // u/2 = sc / (2|major|): scaling by two is exact, so fma(u/2, S, S/2 - 0.5) == fma(u, S/2, S/2 - 0.5) bit for bit
+    float uh = 0.f, vh = 0.f;
+    if (ma2 > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma2); uh = sc * inv; vh = tc * inv; }
+    const float Sf = f.half_s + f.half_s;
+    const float fx = fmaf(uh, Sf, f.half_s_m05), fy = fmaf(vh, Sf, f.half_s_m05);
     const float x0 = floorf(fx), y0 = floorf(fy);
     // EXACT keeps the oracle's fx - floor(fx); the fast path uses v_fract_f32 (identical except that a weight that
     // would round up to exactly 1.0 is returned as the largest float below 1)
     tx = EXACT ? fx - x0 : __builtin_amdgcn_fractf(fx);
     ty = EXACT ? fy - y0 : __builtin_amdgcn_fractf(fy);
-    // |sc|, |tc| <= ma, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
-    // the clamp-addressing of the footprint table never needs a min/max here (NaN converts to 0, also in range).
-    const int ix = (int)x0 + 1, iy = (int)y0 + 1;                                             // [0, S]
-    // 24-bit multiply (full rate), 32-bit unsigned offset: (face*S1 + iy)*S1 + ix < 2^24 for S <= 1024
-    return (unsigned)__mul24(frow + iy, S1) + (unsigned)ix;
+    // |sc|, |tc| <= |major|, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
+    // the clamp-addressing of the footprint table never needs a min/max here.  The footprint index
+    // (face*(S+1) + y0+1)*(S+1) + x0+1 is formed in float (exact: all values are small integers), one conversion.
+    const float S1f = Sf + 1.0f;
+    return (unsigned)fmaf(fmaf(fid, S1f, y0 + 1.0f), S1f, x0 + 1.0f);
 }
 
 template <bool EXACT>
