@@ -26,6 +26,7 @@
 namespace {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pack_half2(float a, float b)
 {
@@ -107,17 +108,24 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /
     const float a = fmaf(tx, q.z - q.x, q.x), b = fmaf(tx, q.w - q.y, q.y);
     const float raw = fmaf(ty, b - a, a);
     net = fmaf(f.D, raw, f.one_minus_D);                                          // netDisplacement   :119
-    const float d2q = 4.0f * d2;                                                  // dot(2ps, 2ps)     :121
-    float t = fdiv<EXACT>(d2q - net, 0.7f * net - net);                           // smoothstep        :126
-    t = fminf(fmaxf(t, 0.f), 1.f);
+    float t;
+    if (EXACT) {
+        const float d2q = 4.0f * d2;                                              // dot(2ps, 2ps)     :121
+        t = (d2q - net) / (0.7f * net - net);                                     // smoothstep(net, 0.7 net, d2q) :126
+        t = fminf(fmaxf(t, 0.f), 1.f);
+    } else {
+        // same quantity, (4 d2 - net) / (-0.3 net) = 10/3 - (40/3) d2 / net, as reciprocal + multiply + fused clamp
+        t = __builtin_amdgcn_fmed3f(fmaf(d2 * __builtin_amdgcn_rcpf(net), -13.333333f, 3.3333333f), 0.f, 1.f);
+    }
     const float base = (t * t) * (3.0f - 2.0f * t);
-    den = (base * f.opacity_factor) * opw;      // :127, :130-131 (opw = 1.0 exactly when _FadeOutParticles is off)
+    // :127, :130-131.  opw = 1.0 exactly when _FadeOutParticles is off; the fast path folds the two factors (one rounding less)
+    den = EXACT ? (base * f.opacity_factor) * opw : base * (f.opacity_factor * opw);
 }
 
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
 // (propagation with T_in = 1) to light_out.
 template <int NV, bool EXACT, int MODE>
-__global__ void __launch_bounds__(256, 4)      // <= 128 VGPRs: 4 waves per SIMD
+__global__ void __launch_bounds__(256)
 k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
@@ -226,22 +234,69 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 const uint32_t wm = wave_or(m);
                 if (wm == 0) continue;
                 const int s_first = __builtin_ctz(wm), s_last = 31 - __builtin_clz(wm);
-#pragma unroll 1
-                for (int s = s_first; s <= s_last; ++s) {
+                // Two-stage software pipeline over the slices of the range (>= 99 % of them contain a covered voxel):
+                //   stage 1: coverage test, cube addressing, footprint load ISSUED (one load per slice, every lane; lanes
+                //            without a covered voxel fetch entry 0, an L1 hit)
+                //   stage 2: wait for that load only, bilinear + smoothstep + accumulate
+                // with two register sets (a, b), so the load of slice s+1 is in flight while slice s is shaded.  hipcc
+                // cannot express "wait for the older of two loads" here (it emits vmcnt(0) around exec-masked regions),
+                // so the load and its wait are inline asm: loads return in order, hence vmcnt(1) == "the older one landed".
+                auto stage1 = [&](int s, float& tx, float& ty, float& d2, bool& hit, f32x4& q) {
                     const float fs = (float)(c0 + s);
                     const float psx = fmaf(fs, Bx, Ax), psy = fmaf(fs, By, Ay), psz = fmaf(fs, Bz, Az);
-                    const float d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
-                    const bool hit = d2 <= 0.25f;                                        // Fill.shader:172,196
-                    if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                    d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
+                    hit = d2 <= 0.25f;                                                   // Fill.shader:172,196
+                    const unsigned qi = cube_address<EXACT>(f, psx, psy, psz, tx, ty);
+                    const unsigned off = hit ? qi * 16u : 0u;
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
+                };
+                auto stage2 = [&](int s, float tx, float ty, float d2, bool hit, const f32x4& q) {
                     if (hit) {
-                        float tx, ty, den, net;
-                        const unsigned qi = cube_address<EXACT>(f, psx, psy, psz, tx, ty);
-                        cube_shade<EXACT>(f, p_cubequads[qi], tx, ty, d2, opacity, den, net);
+                        float den, net;
+                        cube_shade<EXACT>(f, make_float4(q[0], q[1], q[2], q[3]), tx, ty, d2, opacity, den, net);
                         dens[s] += den;                                                  // :200
                         // ao = max(ao, net) (:201); both are >= 0, so the max of the bit patterns is the float max
                         ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
                     }
+                };
+                // Groups of four / two / one slices; inside a group the loads alternate between the two register sets and
+                // nothing in flight crosses a branch or a loop back-edge (the compiler may copy registers there, and a copy
+                // of a register whose load has not landed would read stale data).
+#define VPFX_WAIT_VM(N, Q) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(Q) : : "memory")
+                int s = s_first;
+#pragma unroll 1
+                for (; s + 3 <= s_last; s += 4) {
+                    float txa, tya, d2a, txb, tyb, d2b; bool hita, hitb; f32x4 qa, qb;
+                    stage1(s, txa, tya, d2a, hita, qa);
+                    stage1(s + 1, txb, tyb, d2b, hitb, qb);
+                    VPFX_WAIT_VM(1, qa);
+                    stage2(s, txa, tya, d2a, hita, qa);
+                    stage1(s + 2, txa, tya, d2a, hita, qa);
+                    VPFX_WAIT_VM(1, qb);
+                    stage2(s + 1, txb, tyb, d2b, hitb, qb);
+                    stage1(s + 3, txb, tyb, d2b, hitb, qb);
+                    VPFX_WAIT_VM(1, qa);
+                    stage2(s + 2, txa, tya, d2a, hita, qa);
+                    VPFX_WAIT_VM(0, qb);
+                    stage2(s + 3, txb, tyb, d2b, hitb, qb);
                 }
+                if (s + 1 <= s_last) {
+                    float txa, tya, d2a, txb, tyb, d2b; bool hita, hitb; f32x4 qa, qb;
+                    stage1(s, txa, tya, d2a, hita, qa);
+                    stage1(s + 1, txb, tyb, d2b, hitb, qb);
+                    VPFX_WAIT_VM(1, qa);
+                    stage2(s, txa, tya, d2a, hita, qa);
+                    VPFX_WAIT_VM(0, qb);
+                    stage2(s + 1, txb, tyb, d2b, hitb, qb);
+                    s += 2;
+                }
+                if (s <= s_last) {
+                    float txa, tya, d2a; bool hita; f32x4 qa;
+                    stage1(s, txa, tya, d2a, hita, qa);
+                    VPFX_WAIT_VM(0, qa);
+                    stage2(s, txa, tya, d2a, hita, qa);
+                }
+#undef VPFX_WAIT_VM
             }
             }
 
