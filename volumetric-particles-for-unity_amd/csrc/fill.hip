@@ -265,6 +265,28 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 #define VPFX_WAIT_VM(N, Q) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(Q) : : "memory")
                 int s = s_first;
 #pragma unroll 1
+                for (; s + 5 <= s_last; s += 6) {            // three loads in flight
+                    float txa, tya, d2a, txb, tyb, d2b, txc, tyc, d2c; bool hita, hitb, hitc; f32x4 qa, qb, qc;
+                    stage1(s, txa, tya, d2a, hita, qa);
+                    stage1(s + 1, txb, tyb, d2b, hitb, qb);
+                    stage1(s + 2, txc, tyc, d2c, hitc, qc);
+                    VPFX_WAIT_VM(2, qa);
+                    stage2(s, txa, tya, d2a, hita, qa);
+                    stage1(s + 3, txa, tya, d2a, hita, qa);
+                    VPFX_WAIT_VM(2, qb);
+                    stage2(s + 1, txb, tyb, d2b, hitb, qb);
+                    stage1(s + 4, txb, tyb, d2b, hitb, qb);
+                    VPFX_WAIT_VM(2, qc);
+                    stage2(s + 2, txc, tyc, d2c, hitc, qc);
+                    stage1(s + 5, txc, tyc, d2c, hitc, qc);
+                    VPFX_WAIT_VM(2, qa);
+                    stage2(s + 3, txa, tya, d2a, hita, qa);
+                    VPFX_WAIT_VM(1, qb);
+                    stage2(s + 4, txb, tyb, d2b, hitb, qb);
+                    VPFX_WAIT_VM(0, qc);
+                    stage2(s + 5, txc, tyc, d2c, hitc, qc);
+                }
+#pragma unroll 1
                 for (; s + 3 <= s_last; s += 4) {
                     float txa, tya, d2a, txb, tyb, d2b; bool hita, hitb; f32x4 qa, qb;
                     stage1(s, txa, tya, d2a, hita, qa);
