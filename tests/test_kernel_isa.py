@@ -1,0 +1,39 @@
+"""CPU: static properties of the generated gfx950 ISA that the fill kernel's correctness and speed rely on (hipcc
+cross-compiles without a GPU).  See scripts/check_fill_asm.py for the hazard being excluded."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc", "fill.hip")
+
+
+def test_pipelined_footprint_loads_are_never_touched_before_their_wait():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"(\d+) pipelined loads, 0 violations", r.stdout)
+    assert m and int(m.group(1)) > 100, r.stdout
+
+
+def test_fill_kernel_resources():
+    """No scratch, register arrays addressed through s_set_gpr_idx (not compare/select chains), <= 168 VGPRs (3 waves/SIMD)."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                          "--cuda-device-only", "-S", SRC, "-o", "/dev/stdout", "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, check=True)
+    blocks = re.split(r"Function Name: ", out.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "k_fillILi" not in name:
+            continue
+        seen += 1
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 168, name
+    assert seen == 12
+    asm = out.stdout
+    body = asm[asm.index("k_fillILi32ELb0ELi0"):]
+    body = body[:body.index("s_endpgm")]
+    assert body.count("s_set_gpr_idx_on") >= 8
+    assert body.count("v_cndmask") < 200            # a compare/select lowering of the 32-entry arrays would be thousands
+    assert body.count("v_cubeid_f32") >= 4

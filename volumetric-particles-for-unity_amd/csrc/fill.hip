@@ -20,8 +20,13 @@
 //     instead of four texel fetches (gfx950 has no image/sampler hardware).
 // Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernel is ALU-limited well before it.
 #include <cstdlib>
+#include <type_traits>
 
 #include "vpfx_internal.h"
+
+#ifndef VPFX_FILL_PIPE
+#define VPFX_FILL_PIPE 4      // at most 4 (deeper groups were measured: no further gain)
+#endif
 
 namespace {
 
@@ -44,6 +49,19 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// s_waitcnt vmcnt(N) that also "touches" the destination registers of the load being waited for, so that the compiler
+// orders every later use of Q after the wait (it cannot see the asynchronous write of the inline-asm load).
+template <int N>
+__device__ __forceinline__ void wait_vm(f32x4& q) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "n"(N) : "memory"); }
+// drain phase of a group of depth D: slot i still has D-1-i younger loads behind it
+template <int D>
+__device__ __forceinline__ void wait_vm_dyn(int i, f32x4& q)
+{
+    if (D - 1 - i >= 7) wait_vm<7>(q); else if (D - 1 - i == 6) wait_vm<6>(q); else if (D - 1 - i == 5) wait_vm<5>(q);
+    else if (D - 1 - i == 4) wait_vm<4>(q); else if (D - 1 - i == 3) wait_vm<3>(q); else if (D - 1 - i == 2) wait_vm<2>(q);
+    else if (D - 1 - i == 1) wait_vm<1>(q); else wait_vm<0>(q);
 }
 
 template <bool EXACT>
@@ -129,6 +147,7 @@ __global__ void __launch_bounds__(256)
 k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
+    constexpr int PIPE = VPFX_FILL_PIPE;             // footprint loads in flight per wave
     constexpr int TW = NV / 16;                      // 16x16-column tiles per MV edge
     constexpr int TPM = TW * TW;
     const int col = p_colorder[blockIdx.x / TPM];
@@ -259,66 +278,44 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                         ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
                     }
                 };
-                // Groups of four / two / one slices; inside a group the loads alternate between the two register sets and
-                // nothing in flight crosses a branch or a loop back-edge (the compiler may copy registers there, and a copy
-                // of a register whose load has not landed would read stale data).
-#define VPFX_WAIT_VM(N, Q) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(Q) : : "memory")
-                int s = s_first;
+                // Slices are processed in groups of 2*D (D = loads in flight) with D register sets; inside a group nothing in
+                // flight crosses a branch or a loop back-edge (the compiler may copy registers there, and a copy of a register
+                // whose load has not landed would read stale data).  Remainders fall through to smaller groups.
+                int s_next = s_first;
+                auto group = [&](auto depth) {
+                    constexpr int D = decltype(depth)::value;
+                    const int s = s_next;
+                    float tx[D], ty[D], d2[D]; bool hit[D]; f32x4 q[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) stage1(s + i, tx[i], ty[i], d2[i], hit[i], q[i]);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        wait_vm<D - 1>(q[i]);
+                        stage2(s + i, tx[i], ty[i], d2[i], hit[i], q[i]);
+                        stage1(s + D + i, tx[i], ty[i], d2[i], hit[i], q[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        wait_vm_dyn<D>(i, q[i]);
+                        stage2(s + D + i, tx[i], ty[i], d2[i], hit[i], q[i]);
+                    }
+                    s_next = s + 2 * D;
+                };
+                // full groups of 2*PIPE slices, then (at most) one group of each smaller depth: with PIPE = 4 the remainder is
+                // < 8 slices, so {6, 4, 2} + 1 covers it
+                static_assert(PIPE == 4, "the remainder schedule below is written for PIPE = 4");
 #pragma unroll 1
-                for (; s + 5 <= s_last; s += 6) {            // three loads in flight
-                    float txa, tya, d2a, txb, tyb, d2b, txc, tyc, d2c; bool hita, hitb, hitc; f32x4 qa, qb, qc;
-                    stage1(s, txa, tya, d2a, hita, qa);
-                    stage1(s + 1, txb, tyb, d2b, hitb, qb);
-                    stage1(s + 2, txc, tyc, d2c, hitc, qc);
-                    VPFX_WAIT_VM(2, qa);
-                    stage2(s, txa, tya, d2a, hita, qa);
-                    stage1(s + 3, txa, tya, d2a, hita, qa);
-                    VPFX_WAIT_VM(2, qb);
-                    stage2(s + 1, txb, tyb, d2b, hitb, qb);
-                    stage1(s + 4, txb, tyb, d2b, hitb, qb);
-                    VPFX_WAIT_VM(2, qc);
-                    stage2(s + 2, txc, tyc, d2c, hitc, qc);
-                    stage1(s + 5, txc, tyc, d2c, hitc, qc);
-                    VPFX_WAIT_VM(2, qa);
-                    stage2(s + 3, txa, tya, d2a, hita, qa);
-                    VPFX_WAIT_VM(1, qb);
-                    stage2(s + 4, txb, tyb, d2b, hitb, qb);
-                    VPFX_WAIT_VM(0, qc);
-                    stage2(s + 5, txc, tyc, d2c, hitc, qc);
+                while (s_next + 7 <= s_last) group(std::integral_constant<int, 4>{});
+                if (s_next + 5 <= s_last) group(std::integral_constant<int, 3>{});
+                if (s_next + 3 <= s_last) group(std::integral_constant<int, 2>{});
+                if (s_next + 1 <= s_last) group(std::integral_constant<int, 1>{});
+                if (s_next <= s_last) {
+                    const int s = s_next;
+                    float tx, ty, d2; bool hit; f32x4 q;
+                    stage1(s, tx, ty, d2, hit, q);
+                    wait_vm<0>(q);
+                    stage2(s, tx, ty, d2, hit, q);
                 }
-#pragma unroll 1
-                for (; s + 3 <= s_last; s += 4) {
-                    float txa, tya, d2a, txb, tyb, d2b; bool hita, hitb; f32x4 qa, qb;
-                    stage1(s, txa, tya, d2a, hita, qa);
-                    stage1(s + 1, txb, tyb, d2b, hitb, qb);
-                    VPFX_WAIT_VM(1, qa);
-                    stage2(s, txa, tya, d2a, hita, qa);
-                    stage1(s + 2, txa, tya, d2a, hita, qa);
-                    VPFX_WAIT_VM(1, qb);
-                    stage2(s + 1, txb, tyb, d2b, hitb, qb);
-                    stage1(s + 3, txb, tyb, d2b, hitb, qb);
-                    VPFX_WAIT_VM(1, qa);
-                    stage2(s + 2, txa, tya, d2a, hita, qa);
-                    VPFX_WAIT_VM(0, qb);
-                    stage2(s + 3, txb, tyb, d2b, hitb, qb);
-                }
-                if (s + 1 <= s_last) {
-                    float txa, tya, d2a, txb, tyb, d2b; bool hita, hitb; f32x4 qa, qb;
-                    stage1(s, txa, tya, d2a, hita, qa);
-                    stage1(s + 1, txb, tyb, d2b, hitb, qb);
-                    VPFX_WAIT_VM(1, qa);
-                    stage2(s, txa, tya, d2a, hita, qa);
-                    VPFX_WAIT_VM(0, qb);
-                    stage2(s + 1, txb, tyb, d2b, hitb, qb);
-                    s += 2;
-                }
-                if (s <= s_last) {
-                    float txa, tya, d2a; bool hita; f32x4 qa;
-                    stage1(s, txa, tya, d2a, hita, qa);
-                    VPFX_WAIT_VM(0, qa);
-                    stage2(s, txa, tya, d2a, hita, qa);
-                }
-#undef VPFX_WAIT_VM
             }
             }
 
