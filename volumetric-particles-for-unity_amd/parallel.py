@@ -76,6 +76,22 @@ class SlabPipeline:
 
     def __init__(self, engine, bounds, rank: int, world: int, group=None):
         self.eng, self.bounds, self.rank, self.world, self.group = engine, list(bounds), rank, world, group
+        self._tau_all = None       # [world, LH, LW] receive buffer of the transmittance all-gather
+        self._img_all = None       # [world, H, W, 4] receive buffer of the partial-image all-gather
+        self._second = None
+        self._into_tensor = True   # all_gather_into_tensor (one contiguous receive buffer, no per-rank copies) if supported
+
+    def _all_gather(self, buf, src):
+        """all-gather `src` into the preallocated [world, ...] buffer `buf`; returns the per-rank views."""
+        if self._into_tensor:
+            try:
+                dist.all_gather_into_tensor(buf, src, group=self.group)
+                return list(buf.unbind(0))
+            except (RuntimeError, NotImplementedError):
+                self._into_tensor = False          # backend without the fused form (older gloo): list form below
+        parts = list(buf.unbind(0))
+        dist.all_gather(parts, src, group=self.group)
+        return parts
 
     def fill(self, fill_params):
         self.eng.bin_resident()
@@ -83,8 +99,9 @@ class SlabPipeline:
             self.eng.fill(fill_params)
             return
         tau = self.eng.fill_local(fill_params)
-        taus = [torch.empty_like(tau) for _ in range(self.world)]
-        dist.all_gather(taus, tau, group=self.group)
+        if self._tau_all is None:
+            self._tau_all = torch.empty((self.world,) + tuple(tau.shape), dtype=tau.dtype, device=tau.device)
+        taus = self._all_gather(self._tau_all, tau)
         t_in = None
         for r in range(self.rank):                 # product in slab order, like the sequential light map
             t_in = taus[r].clone() if t_in is None else t_in.mul_(taus[r])
@@ -98,11 +115,17 @@ class SlabPipeline:
         over, under = self.eng.raymarch_partial(cam, rp)
         z0, z1 = self.bounds[self.rank]
         primary = over if z0 <= zb else under      # the straddler's primary is its OVER image
-        prim = [torch.empty_like(primary) for _ in range(self.world)]
-        dist.all_gather(prim, primary, group=self.group)
+        if self._img_all is None:
+            self._img_all = torch.empty((self.world,) + tuple(primary.shape), dtype=primary.dtype, device=primary.device)
+        prim = self._all_gather(self._img_all, primary)
         second = None
         if straddler is not None:
-            second = under if self.rank == straddler else torch.empty_like(under)
+            if self.rank == straddler:
+                second = under
+            else:
+                if self._second is None:
+                    self._second = torch.empty_like(under)
+                second = self._second
             dist.broadcast(second, src=straddler, group=self.group)
         images, kinds = [], []
         for r, which, kind in plan:
