@@ -3,7 +3,7 @@
 //
 //   k_extract      caller records (AoS, arbitrary stride) -> SoA (world pos, size) + 64-byte fill record
 //   k_bin<COUNT>   one thread per particle: candidate range + exact sphere/bordered-box test, atomic count
-//   k_scan         single-workgroup exclusive scan: CSR offsets, brick slots (z-major = draw order), totals
+//   k_scan_*       two-launch tiled exclusive scan: CSR offsets, brick slots (z-major = draw order), totals
 //   k_bin<SCATTER> same walk, atomic cursor -> unsorted CSR lists
 //   k_sort_lists   per occupied MV: rank sort -> ascending particle index (the reference's list order, :452)
 //   k_col_order    MV columns sorted by work, heaviest first (launch order of the persistent fill kernel)
@@ -144,43 +144,78 @@ k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restri
             }
 }
 
-// Exclusive scan of count[] -> offsets[], brick slots for occupied slab MVs in linear (= z-major draw) order.
-__global__ void __launch_bounds__(1024)
-k_scan(const int* __restrict__ count, int n3, int nxy, int z0, int z1, int* __restrict__ offsets,
-       int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor, DevMeta* __restrict__ meta)
+// Exclusive scan of count[] -> offsets[], brick slots for occupied slab MVs in linear (= z-major draw) order, in two
+// fully coalesced launches over tiles of 1024 MVs: k_scan_tiles (per-tile totals) and k_scan_write (every workgroup
+// re-reduces the <= 256 tile totals in front of it -- cheaper than a third launch -- then scans and writes its tile).
+#define SCAN_TILE 1024
+struct TileTotals { int pairs, occ, mx, pad; };
+
+__device__ __forceinline__ void block_scan3(int& a, int& b, int& m, int* sh /* [3][16] */)
 {
-    __shared__ int s_pairs[1024], s_occ[1024], s_max[1024];
-    const int t = threadIdx.x;
-    const int per = (n3 + 1023) / 1024;
-    const int lo = min(t * per, n3), hi = min(lo + per, n3);
-    int sp = 0, so = 0, mx = 0;
-    for (int i = lo; i < hi; ++i) {
-        const int cnt = count[i];
-        const int zz = i / nxy;
-        sp += cnt; so += (cnt != 0 && zz >= z0 && zz < z1) ? 1 : 0; mx = max(mx, cnt);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int ua = __shfl_up(a, d), ub = __shfl_up(b, d), um = __shfl_up(m, d);
+        if (lane >= d) { a += ua; b += ub; m = max(m, um); }
     }
-    s_pairs[t] = sp; s_occ[t] = so; s_max[t] = mx;
+    if (lane == 63) { sh[wv] = a; sh[16 + wv] = b; sh[32 + wv] = m; }
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
-        int a = 0, b = 0, m = 0;
-        if (t >= d) { a = s_pairs[t - d]; b = s_occ[t - d]; m = s_max[t - d]; }
-        __syncthreads();
-        if (t >= d) { s_pairs[t] += a; s_occ[t] += b; s_max[t] = max(s_max[t], m); }
-        __syncthreads();
+    int ba = 0, bb = 0, gm = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) { ba += sh[w]; bb += sh[16 + w]; }
+        gm = max(gm, sh[32 + w]);
     }
-    int bp = s_pairs[t] - sp, bo = s_occ[t] - so;
-    for (int i = lo; i < hi; ++i) {
-        const int cnt = count[i];
-        const int zz = i / nxy;
-        offsets[i] = bp; cursor[i] = 0;
-        const bool occ = (cnt != 0 && zz >= z0 && zz < z1);                  // VPR.cs:511
-        brick_index[i] = occ ? bo : -1;
-        if (occ) occ_list[bo] = i;
-        bp += cnt; bo += occ ? 1 : 0;
+    a += ba; b += bb; m = gm;                        // inclusive over the workgroup; m = workgroup max
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(SCAN_TILE)
+k_scan_tiles(const int* __restrict__ count, int n3, int nxy, int z0, int z1, TileTotals* __restrict__ totals)
+{
+    __shared__ int sh[48];
+    const int i = blockIdx.x * SCAN_TILE + threadIdx.x;
+    const int cnt = i < n3 ? count[i] : 0;
+    const int zz = i / nxy;
+    int a = cnt, b = (cnt != 0 && zz >= z0 && zz < z1) ? 1 : 0, m = cnt;
+    block_scan3(a, b, m, sh);
+    if (threadIdx.x == SCAN_TILE - 1) totals[blockIdx.x] = TileTotals{a, b, m, 0};
+}
+
+__global__ void __launch_bounds__(SCAN_TILE)
+k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, const TileTotals* __restrict__ totals, int ntiles,
+             int* __restrict__ offsets, int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor,
+             DevMeta* __restrict__ meta)
+{
+    __shared__ int sh[48];
+    __shared__ int s_base[3];
+    // exclusive prefix of the tile totals in front of this tile (and the grand totals, for the last workgroup)
+    int pa = 0, pb = 0, pm = 0;
+    for (int t = threadIdx.x; t < ntiles; t += SCAN_TILE) {
+        const TileTotals tt = totals[t];
+        if (t < (int)blockIdx.x) { pa += tt.pairs; pb += tt.occ; }
+        pm = max(pm, tt.mx);
     }
-    if (t == 1023) {
-        offsets[n3] = s_pairs[1023];
-        meta->occupied = s_occ[1023]; meta->pairs = s_pairs[1023]; meta->max_pairs = s_max[1023];
+    block_scan3(pa, pb, pm, sh);
+    if (threadIdx.x == SCAN_TILE - 1) { s_base[0] = pa; s_base[1] = pb; s_base[2] = pm; }
+    __syncthreads();
+    const int base_pairs = s_base[0], base_occ = s_base[1], gmax = s_base[2];
+    const int i = blockIdx.x * SCAN_TILE + threadIdx.x;
+    const int cnt = i < n3 ? count[i] : 0;
+    const int zz = i / nxy;
+    const bool occ = cnt != 0 && zz >= z0 && zz < z1;                       // VPR.cs:511
+    int a = cnt, b = occ ? 1 : 0, m = cnt;
+    block_scan3(a, b, m, sh);
+    if (i < n3) {
+        offsets[i] = base_pairs + a - cnt;
+        cursor[i] = 0;
+        const int slot = base_occ + b - (occ ? 1 : 0);
+        brick_index[i] = occ ? slot : -1;
+        if (occ) occ_list[slot] = i;
+    }
+    if ((int)blockIdx.x == ntiles - 1 && threadIdx.x == SCAN_TILE - 1) {
+        offsets[n3] = base_pairs + a;
+        meta->occupied = base_occ + b; meta->pairs = base_pairs + a; meta->max_pairs = gmax;
         meta->unsorted_lists = 0;
     }
 }
@@ -214,18 +249,26 @@ k_sort_lists(const int* __restrict__ occ_list, const int* __restrict__ offsets, 
 __global__ void __launch_bounds__(1024)
 k_col_order(const int* __restrict__ count, int nxy, int z0, int z1, int* __restrict__ colorder)
 {
-    __shared__ int s_work[COL_CAP];
+    __shared__ __attribute__((aligned(16))) int s_work[COL_CAP];
     if (nxy > COL_CAP) { for (int i = threadIdx.x; i < nxy; i += 1024) colorder[i] = i; return; }
     for (int i = threadIdx.x; i < nxy; i += 1024) {
         int wsum = 0;
+#pragma unroll 8
         for (int zz = z0; zz < z1; ++zz) { const int cnt = count[zz * nxy + i]; wsum += cnt ? cnt + 8 : 0; }
         s_work[i] = wsum;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nxy; i += 1024) {
         const int w = s_work[i];
-        int rank = 0;
-        for (int j = 0; j < nxy; ++j) { const int wj = s_work[j]; rank += (wj > w || (wj == w && j < i)) ? 1 : 0; }
+        int rank = 0, j = 0;
+        for (; j + 4 <= nxy; j += 4) {                       // one 16-byte LDS broadcast read per four candidates
+            const int4 q = *reinterpret_cast<const int4*>(&s_work[j]);
+            rank += (q.x > w || (q.x == w && j < i)) ? 1 : 0;
+            rank += (q.y > w || (q.y == w && j + 1 < i)) ? 1 : 0;
+            rank += (q.z > w || (q.z == w && j + 2 < i)) ? 1 : 0;
+            rank += (q.w > w || (q.w == w && j + 3 < i)) ? 1 : 0;
+        }
+        for (; j < nxy; ++j) { const int wj = s_work[j]; rank += (wj > w || (wj == w && j < i)) ? 1 : 0; }
         colorder[rank] = i;
     }
 }
@@ -263,8 +306,11 @@ int launch_bin(vp_ctx* c)
         hipLaunchKernelGGL(k_bin<0>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_count,
                            (const int*)nullptr, (int*)nullptr, c->d_rec);
     }
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1, c->d_offsets,
-                       c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
+    const int ntiles = (n3 + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
+                       (TileTotals*)c->d_scan_totals);
+    hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
+                       (const TileTotals*)c->d_scan_totals, ntiles, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
     hipLaunchKernelGGL(k_col_order, dim3(1), dim3(1024), 0, c->stream, c->d_count, nxy, g.z0, g.z1, c->d_colorder);
     VP_HIP(hipGetLastError());
     // totals are needed on the host to size the pair and brick pools

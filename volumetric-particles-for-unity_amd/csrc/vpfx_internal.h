@@ -103,6 +103,7 @@ struct vp_ctx {
     size_t pairs_cap = 0;
     int* d_colorder = nullptr;    // [Nx*Ny] MV columns, heaviest first
     DevMeta* d_meta = nullptr;
+    void* d_scan_totals = nullptr; // [ceil(N^3 / 1024)] per-tile totals of the two-launch scan
     DevMeta h_meta{};
 
     // fill
