@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""Static check of the software-pipelined footprint loads in k_fill (csrc/fill.hip).
+"""Static check of the software-pipelined inline-asm loads in k_fill (csrc/fill.hip) and k_raymarch (csrc/raymarch.hip).
 
 The loads are inline asm (`global_load_dwordx4 vDST, vOFF, s[..]`) whose asynchronous register write the compiler cannot see;
 correctness needs that NO instruction reads or writes vDST between the load and the `s_waitcnt vmcnt(N)` that retires it
 (loads return in order, so a wait with N younger loads outstanding retires it).  The compiler is free to insert register copies,
 so this script re-derives the property from the generated ISA of every k_fill instantiation and fails loudly if it is violated.
-usage: check_fill_asm.py [path/to/fill.hip]      (compiles to asm with hipcc; exit code 1 on violation)"""
+The same holds for the explicitly issued texel loads of k_raymarch's two-sample loop (vaddr form); there every 16-byte global
+load of the kernel is tracked (the compiler's own loads satisfy the property by construction).
+usage: check_fill_asm.py [fill|raymarch] [extra hipcc flags]      (compiles to asm with hipcc; exit code 1 on violation)"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc", "fill.hip")
-EXTRA = sys.argv[2:] 
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "fill"
+CSRC = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
+SRC = WHICH if WHICH.endswith(".hip") else os.path.join(CSRC, WHICH + ".hip")
+KERNEL = "k_raymarch" if "raymarch" in os.path.basename(SRC) else "k_fill"
+LOAD_RE = (r"global_load_dwordx4\s+(v\[\d+:\d+\]),\s*v\[\d+:\d+\],\s*off" if KERNEL == "k_raymarch"
+           else r"global_load_dwordx4\s+(v\[\d+:\d+\]),\s*v\d+,\s*s\[\d+:\d+\]")
+EXTRA = sys.argv[2:]
 
 
 def regs(tok):
@@ -32,7 +39,7 @@ def check_kernel(lines):
         if not t or t.endswith(":") or t.startswith("."):
             continue
         op = t.split()[0]
-        m = re.match(r"global_load_dwordx4\s+(v\[\d+:\d+\]),\s*v\d+,\s*s\[\d+:\d+\]", t)
+        m = re.match(LOAD_RE, t)
         if m:
             outstanding.append((regs(m.group(1)), no))
             continue
@@ -59,7 +66,7 @@ def main():
         txt = open(out).read().split("\n")
     kernels, cur = {}, None
     for i, l in enumerate(txt):
-        m = re.match(r"^(_ZN\S*k_fill\S*):", l)
+        m = re.match(r"^(_ZN\S*" + KERNEL + r"\S*):", l)
         if m:
             cur = []
             kernels[m.group(1)] = cur
@@ -69,11 +76,11 @@ def main():
                 cur = None
     nbad, nloads = 0, 0
     for name, lines in kernels.items():
-        nloads += sum(1 for _, l in lines if re.search(r"global_load_dwordx4\s+v\[\d+:\d+\],\s*v\d+,\s*s\[", l))
+        nloads += sum(1 for _, l in lines if re.search(LOAD_RE, l))
         for no, t, lno in check_kernel(lines):
             print(f"VIOLATION in {name[:70]}: line {no}: '{t}' touches the destination of the load issued at line {lno}")
             nbad += 1
-    print(f"checked {len(kernels)} k_fill instantiations, {nloads} pipelined loads, {nbad} violations")
+    print(f"checked {len(kernels)} {KERNEL} instantiations, {nloads} pipelined loads, {nbad} violations")
     return 1 if nbad or not nloads else 0
 
 

@@ -16,6 +16,13 @@ def test_pipelined_footprint_loads_are_never_touched_before_their_wait():
     assert m and int(m.group(1)) > 100, r.stdout
 
 
+def test_raymarch_texel_loads_are_never_touched_before_their_wait():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py"), "raymarch"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"(\d+) pipelined loads, 0 violations", r.stdout)
+    assert m and int(m.group(1)) >= 96, r.stdout
+
+
 def test_fill_kernel_resources():
     """No scratch, register arrays addressed through s_set_gpr_idx (not compare/select chains), <= 168 VGPRs (3 waves/SIMD)."""
     out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",

@@ -40,6 +40,23 @@ struct __attribute__((aligned(8))) TexelPair { uint32_t rg0, ba0, rg1, ba1; };
 __device__ __forceinline__ float mix_lerp_lo(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(0) return d; }
 __device__ __forceinline__ float mix_lerp_hi(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(1) return d; }
 
+// Explicitly issued 16-byte loads for the two-samples-per-iteration loop: the compiler otherwise sinks the second
+// sample's loads below the first sample's filter (four loads in flight instead of eight).  The asynchronous register
+// write is invisible to the compiler, so wait_quad() takes the destinations as in/out operands: every use is ordered
+// after the s_waitcnt.  scripts/check_fill_asm.py verifies the generated ISA (no access to a destination before its wait).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void issue_load16(u32x4& q, const void* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_quad(u32x4& a, u32x4& b, u32x4& c, u32x4& d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+__device__ __forceinline__ TexelPair as_pair(const u32x4 q) { return TexelPair{q[0], q[1], q[2], q[3]}; }
+
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 __device__ __forceinline__ F4 lerp4(const F4& a, const F4& b, float t)
 {
@@ -92,56 +109,98 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     const int tCamera = (int)(sqrtf((cx * cx + cy * cy) + cz * cz) / k.mvStep);           // :239
     tEntry = max(tEntry, tCamera);                                                        // :240
     float rr = 0.f, rg = 0.f, rb = 0.f, trans = 1.0f;
-    const float bx = ox + 0.5f, by = oy + 0.5f, bz = oz + 0.5f;
-    // tex3D(_VolumeTexture, samplePos) at lattice index si                                :255-262
-    auto sample = [&](int si) -> F4 {
-        const float t = (float)si * k.mvStep;
-        // samplePos = (mvRayPos + 0.5)(1 - 2 bo) + bo, texel = samplePos*nv - 0.5        :255-258
-        const float fx = fmaf(fmaf(t, R.dx, bx), k.texScale, k.texBias);
-        const float fy = fmaf(fmaf(t, R.dy, by), k.texScale, k.texBias);
-        const float fz = fmaf(fmaf(t, R.dz, bz), k.texScale, k.texBias);
+    // samplePos = (mvRayPos + 0.5)(1 - 2 bo) + bo, texel = samplePos*nv - 0.5 (:255-258) is affine in the lattice index:
+    // texel(si) = f0 + si * fs, one FMA per axis per sample
+    const float f0x = fmaf(ox + 0.5f, k.texScale, k.texBias), f0y = fmaf(oy + 0.5f, k.texScale, k.texBias),
+                f0z = fmaf(oz + 0.5f, k.texScale, k.texBias);
+    const float fsx = (k.mvStep * R.dx) * k.texScale, fsy = (k.mvStep * R.dy) * k.texScale, fsz = (k.mvStep * R.dz) * k.texScale;
+    // tex3D(_VolumeTexture, samplePos) at lattice index si (:255-262), split into address / fetch / filter so that the
+    // loads of two samples can be issued back to back before either is filtered
+    struct Addr { const uint2* p; float wx, wy, wz; int ix, iy, iz; };
+    struct Quad { TexelPair t00, t10, t01, t11; };    // [z][y]: texels (x0, x0+1)
+    auto address = [&](int si) -> Addr {
+        const float fi = (float)si;
+        const float fx = fmaf(fi, fsx, f0x), fy = fmaf(fi, fsy, f0y), fz = fmaf(fi, fsz, f0z);
         const float x0 = floorf(fx), y0 = floorf(fy), z0 = floorf(fz);
-        const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
-        TexelPair t00, t10, t01, t11;    // [z][y]: texels (x0, x0+1)
+        Addr a;
+        a.wx = fx - x0; a.wy = fy - y0; a.wz = fz - z0;
         if (!WRAP) {
             // border >= 1: the 2x2x2 footprint never leaves the brick (texel coords lie in [b-0.5, nv-b-0.5]), so the
             // x-neighbours are one 16-byte load and the y / z neighbours fixed offsets from one base address.
-            const int base = ((int)z0 * NV + (int)y0) * NV + (int)x0;
-            const uint2* p = brick + base;
-            t00 = *reinterpret_cast<const TexelPair*>(p);
-            t10 = *reinterpret_cast<const TexelPair*>(p + NV);
-            t01 = *reinterpret_cast<const TexelPair*>(p + NV * NV);
-            t11 = *reinterpret_cast<const TexelPair*>(p + NV * NV + NV);
+            // (z0*NV + y0)*NV + x0 in float (exact: small integers), one conversion
+            a.p = brick + (int)fmaf(fmaf(z0, (float)NV, y0), (float)NV, x0);
+            a.ix = a.iy = a.iz = 0;
         } else {
-            const int ix0 = (int)x0 & (NV - 1), iy0 = (int)y0 & (NV - 1), iz0 = (int)z0 & (NV - 1);   // wrap = Repeat  VPR.cs:770
+            a.p = brick;
+            a.ix = (int)x0; a.iy = (int)y0; a.iz = (int)z0;
+        }
+        return a;
+    };
+    auto fetch = [&](const Addr& a) -> Quad {
+        Quad q;
+        if (!WRAP) {
+            const uint2* p = a.p;
+            q.t00 = *reinterpret_cast<const TexelPair*>(p);
+            q.t10 = *reinterpret_cast<const TexelPair*>(p + NV);
+            q.t01 = *reinterpret_cast<const TexelPair*>(p + NV * NV);
+            q.t11 = *reinterpret_cast<const TexelPair*>(p + NV * NV + NV);
+        } else {
+            const int ix0 = a.ix & (NV - 1), iy0 = a.iy & (NV - 1), iz0 = a.iz & (NV - 1);           // wrap = Repeat  VPR.cs:770
             const int ix1 = (ix0 + 1) & (NV - 1), iy1 = (iy0 + 1) & (NV - 1), iz1 = (iz0 + 1) & (NV - 1);
             const int r00 = (iz0 * NV + iy0) * NV, r10 = (iz0 * NV + iy1) * NV, r01 = (iz1 * NV + iy0) * NV, r11 = (iz1 * NV + iy1) * NV;
             const uint2 a0 = brick[r00 + ix0], a1 = brick[r00 + ix1], b0 = brick[r10 + ix0], b1 = brick[r10 + ix1];
             const uint2 c0 = brick[r01 + ix0], c1 = brick[r01 + ix1], d0 = brick[r11 + ix0], d1 = brick[r11 + ix1];
-            t00 = TexelPair{a0.x, a0.y, a1.x, a1.y}; t10 = TexelPair{b0.x, b0.y, b1.x, b1.y};
-            t01 = TexelPair{c0.x, c0.y, c1.x, c1.y}; t11 = TexelPair{d0.x, d0.y, d1.x, d1.y};
+            q.t00 = TexelPair{a0.x, a0.y, a1.x, a1.y}; q.t10 = TexelPair{b0.x, b0.y, b1.x, b1.y};
+            q.t01 = TexelPair{c0.x, c0.y, c1.x, c1.y}; q.t11 = TexelPair{d0.x, d0.y, d1.x, d1.y};
         }
-        // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math),
-        // then y and z in f32.
-        const F4 c00 = lerp_x(t00, wx), c10 = lerp_x(t10, wx), c01 = lerp_x(t01, wx), c11 = lerp_x(t11, wx);
-        return lerp4(lerp4(c00, c10, wy), lerp4(c01, c11, wy), wz);
+        return q;
     };
-    auto blend = [&](const F4& c, int si) {
-        float density = c.w;
-        const int dc = si - tCamera;
-        if (dc < k.soft) density *= (float)dc * k.inv_soft;                               // soft particles :267-270
+    // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math), then y
+    // and z in f32.
+    auto filter = [&](const Quad& q, const Addr& a) -> F4 {
+        const F4 c00 = lerp_x(q.t00, a.wx), c10 = lerp_x(q.t10, a.wx), c01 = lerp_x(q.t01, a.wx), c11 = lerp_x(q.t11, a.wx);
+        return lerp4(lerp4(c00, c10, a.wy), lerp4(c01, c11, a.wy), a.wz);
+    };
+    auto blend = [&](const F4& c, float density) {
         const float bf = __builtin_amdgcn_rcpf(1.0f + density);                           // :272
         rr = fmaf(bf, rr - c.x, c.x); rg = fmaf(bf, rg - c.y, c.y); rb = fmaf(bf, rb - c.z, c.z);   // lerp(color, result, bf) :274
         trans *= bf;                                                                      // :275
     };
-    // back to front (:254), two lattice samples per iteration so that eight texel-pair loads are in flight
+    // soft particles (:267-270) only touch lattice indices below tCamera + _SoftDistance; everything farther from the camera
+    // (the bulk, and the part marched first: back to front, :254) runs without the fade.  Two lattice samples per iteration
+    // so that eight texel-pair loads are in flight.
+    const int tSoft = max(tEntry, min(tExit + 1, tCamera + k.soft));
     int si = tExit;
-    for (; si - 1 >= tEntry; si -= 2) {
-        const F4 c0 = sample(si), c1 = sample(si - 1);
-        blend(c0, si);
-        blend(c1, si - 1);
+    for (; si - 1 >= tSoft; si -= 2) {
+        const Addr a0 = address(si), a1 = address(si - 1);
+        Quad q0, q1;
+        if (!WRAP) {
+            u32x4 u0, u1, u2, u3, v0, v1, v2, v3;
+            const uint2* z0p = a0.p + NV * NV; const uint2* z1p = a1.p + NV * NV;       // the z+1 plane is beyond the 12-bit offset
+            issue_load16<0>(u0, a0.p); issue_load16<NV * 8>(u1, a0.p); issue_load16<0>(u2, z0p); issue_load16<NV * 8>(u3, z0p);
+            issue_load16<0>(v0, a1.p); issue_load16<NV * 8>(v1, a1.p); issue_load16<0>(v2, z1p); issue_load16<NV * 8>(v3, z1p);
+            wait_quad<4>(u0, u1, u2, u3);
+            q0 = Quad{as_pair(u0), as_pair(u1), as_pair(u2), as_pair(u3)};
+            const F4 c0 = filter(q0, a0);
+            blend(c0, c0.w);
+            wait_quad<0>(v0, v1, v2, v3);
+            q1 = Quad{as_pair(v0), as_pair(v1), as_pair(v2), as_pair(v3)};
+            const F4 c1 = filter(q1, a1);
+            blend(c1, c1.w);
+        } else {
+            q0 = fetch(a0); q1 = fetch(a1);
+            const F4 c0 = filter(q0, a0);
+            blend(c0, c0.w);
+            const F4 c1 = filter(q1, a1);
+            blend(c1, c1.w);
+        }
     }
-    if (si >= tEntry) blend(sample(si), si);
+    for (; si >= tEntry; --si) {
+        const Addr a = address(si);
+        const F4 c = filter(fetch(a), a);
+        const int dc = si - tCamera;
+        blend(c, dc < k.soft ? c.w * ((float)dc * k.inv_soft) : c.w);
+    }
     const int ns = max(0, tExit - tEntry + 1);
     nsamp += ns;
     src = F4{rr, rg, rb, 1.0f - trans};                                                   // :301
@@ -172,26 +231,122 @@ k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict
     out[i] = make_float4(tr[0], tr[1], tr[2], 0.f);
 }
 
+// Dispatch order of the screen super-tiles (64x32 px): most expensive first, so that the long rays are not what the
+// tail of the launch waits for (per-wave work spans 0 .. ~600 samples; dispatched in raster order ~25 % of the wave
+// slots idle).  Cost estimate per super-tile = fraction of the ray inside occupied metavoxels (x its length in the owned
+// part of the grid), from four of its rays; each ray is probed at 64 points by the 64 lanes of one wave, so the estimate
+// costs ONE dependent load.  k_tile_rank then rank-sorts in LDS.  Scheduling only: the image does not depend on the order.
+#define RM_ORDER_MAX 8192
+__global__ void __launch_bounds__(256)
+k_tile_cost(RmConsts k, const int* __restrict__ brick_index, int sgx, float* __restrict__ cost_out)
+{
+    __shared__ float part[4];
+    const int sti = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float colf = fminf((float)((sti % sgx) * 64 + 16 + 32 * (wave & 1)), (float)k.W - 1.f);
+    const float rowf = fminf((float)((sti / sgx) * 32 + 8 + 16 * (wave >> 1)), (float)k.H - 1.f);
+    float dx = (2.0f * (colf + 0.5f) / (float)k.W) - 1.0f;
+    const float dy = (2.0f * (rowf + 0.5f) / (float)k.H) - 1.0f;
+    dx *= k.aspect;
+    const float dz = k.neg_inv_tan;
+    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float dir[3] = {dx * inv, dy * inv, dz * inv};
+    const float st = k.zMin / dir[2];
+    float o[3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d[r] = (k.c2g[4 * r] * dir[0] + k.c2g[4 * r + 1] * dir[1]) + k.c2g[4 * r + 2] * dir[2];
+        o[r] = d[r] * st + k.c2g[4 * r + 3];
+    }
+    const float dn = 1.0f / sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float lo[3] = {0.f, 0.f, (float)k.z0}, hi[3] = {(float)k.Nx, (float)k.Ny, (float)k.z1};
+    const float cx = k.camg[0] - o[0], cy = k.camg[1] - o[1], cz = k.camg[2] - o[2];
+    float t0 = sqrtf((cx * cx + cy * cy) + cz * cz), t1 = 3.0e38f;          // nothing is sampled behind the camera
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d[r] *= dn;
+        const float iv = 1.0f / d[r];                                       // +-inf for an axis-parallel ray: the slab test still works
+        const float a = iv * (lo[r] - o[r]), b = iv * (hi[r] - o[r]);
+        t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b));
+    }
+    float c = 0.f;
+    if (t0 < t1) {
+        const float t = t0 + (t1 - t0) * (((float)lane + 0.5f) * (1.0f / 64.0f));
+        const int gx = (int)floorf(fmaf(t, d[0], o[0])), gy = (int)floorf(fmaf(t, d[1], o[1])), gz = (int)floorf(fmaf(t, d[2], o[2]));
+        const bool occ = gx >= 0 && gx < k.Nx && gy >= 0 && gy < k.Ny && gz >= k.z0 && gz < k.z1 &&
+                         brick_index[(gz * k.Ny + gy) * k.Nx + gx] >= 0;
+        c = (float)__popcll(__ballot(occ)) * (t1 - t0);
+    }
+    if (lane == 0) part[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cost_out[sti] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// rank of 64 super-tiles per workgroup: wave w counts, for each of them, the costlier tiles among the w-th sixteenth of all
+__global__ void __launch_bounds__(1024)
+k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ order)
+{
+    __shared__ __attribute__((aligned(16))) float cost[RM_ORDER_MAX];
+    __shared__ int rank[64];
+    const int npad = (nsuper + 3) & ~3;
+    for (int i = threadIdx.x; i < npad; i += 1024) cost[i] = i < nsuper ? cost_in[i] : -1.0f;   // padding never outranks a tile
+    if (threadIdx.x < 64) rank[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), chunk = threadIdx.x >> 6;
+    const int per = (((npad + 15) / 16) + 3) & ~3;
+    const int j0 = chunk * per, j1 = min(npad, j0 + per);
+    if (i < nsuper) {
+        const float c = cost[i];
+        int r = 0;
+        for (int j = j0; j < j1; j += 4) {
+            const float4 cj = *reinterpret_cast<const float4*>(&cost[j]);
+            r += (cj.x > c || (cj.x == c && j < i)) ? 1 : 0;
+            r += (cj.y > c || (cj.y == c && j + 1 < i)) ? 1 : 0;
+            r += (cj.z > c || (cj.z == c && j + 2 < i)) ? 1 : 0;
+            r += (cj.w > c || (cj.w == c && j + 3 < i)) ? 1 : 0;
+        }
+        atomicAdd(&rank[threadIdx.x & 63], r);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && i < nsuper) order[rank[threadIdx.x]] = i;
+}
+
 // PARTIAL = false: the reference's single render target.  PARTIAL = true: OVER-phase and UNDER-phase MVs of the
 // owned slab composite into two separate images (multi-GPU partial images).
 // FLAGS = false compiles the vp_raymarch_params.flags paths (UNORM8 emulation, debug views) out of the hot loop.
+// One wave per workgroup (no LDS, no barriers: a finished wave frees its slot at once), five waves per SIMD.
+#ifndef VPFX_RM_WG
+#define VPFX_RM_WG 64
+#endif
+#ifndef VPFX_RM_WAVES
+#define VPFX_RM_WAVES 5
+#endif
+#define VPFX_RM_LB __launch_bounds__(VPFX_RM_WG, VPFX_RM_WAVES)
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
-__global__ void __launch_bounds__(256)
+__global__ void VPFX_RM_LB
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
-           unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, int early_out)
+           unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
 {
+#if VPFX_RM_WG == 256
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#else
+    const int wave = (int)(blockIdx.x >> 3) & 3, lane = threadIdx.x;
+#endif
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
     // has its own L2.  Screen tiles are grouped into 4x2 super-tiles (64x32 px, about one brick's footprint); super-tile
     // i is rendered entirely by XCD i % 8, so a brick is pulled into ~2-4 L2s instead of all eight, while neighbouring
     // super-tiles still alternate XCDs (load balance across the image).
     const int tgx = (k.W + 15) >> 4, tgy = (k.H + 15) >> 4;
     const int sgx = (tgx + 3) >> 2, sgy = (tgy + 1) >> 1;
+#if VPFX_RM_WG == 256
     const int q = (int)(blockIdx.x >> 3);
-    const int sti = (q >> 3) * 8 + (int)(blockIdx.x & 7u);        // super-tile index
+#else
+    const int q = (int)(blockIdx.x >> 5);
+#endif
+    const int slot = (q >> 3) * 8 + (int)(blockIdx.x & 7u);       // position in the dispatch order
     const int j = q & 7;                                          // tile inside the super-tile
-    if (sti >= sgx * sgy) return;
+    if (slot >= sgx * sgy) return;
+    const int sti = tile_order ? tile_order[slot] : slot;         // super-tile index
     const int ttx = (sti % sgx) * 4 + (j & 3), tty = (sti / sgx) * 2 + (j >> 2);
     if (ttx >= tgx || tty >= tgy) return;
     const int col = ttx * 16 + (wave & 1) * 8 + (lane & 7);
@@ -356,10 +511,19 @@ k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, si
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
 void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
 {
-    const int nsuper = ((((k.W + 15) / 16) + 3) / 4) * ((((k.H + 15) / 16) + 1) / 2);
-    const dim3 grid(((nsuper + 7) / 8) * 64), block(256);
+    const int nsuper = rm_num_super_tiles(k.W, k.H);
+    const int* order = nullptr;
+#ifndef VPFX_RM_NO_ORDER
+    if (nsuper <= RM_ORDER_MAX) {
+        float* cost = reinterpret_cast<float*>(c->d_tile_order + nsuper + 8);
+        hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, (((k.W + 15) / 16) + 3) / 4, cost);
+        hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
+        order = c->d_tile_order;
+    }
+#endif
+    const dim3 grid(((nsuper + 7) / 8) * 64 * (256 / VPFX_RM_WG)), block(VPFX_RM_WG);
     hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
-                       c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, early_out);
+                       c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out);
 }
 
 template <int NV>

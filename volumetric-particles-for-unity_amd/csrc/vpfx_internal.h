@@ -127,6 +127,7 @@ struct vp_ctx {
     float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
     size_t mvtrans_cap = 0;
     int* d_rank = nullptr;        // [Ny*Nx]
+    int* d_tile_order = nullptr;  // [2 x (super-tiles + 8)] dispatch order of k_raymarch (most expensive first), then the float cost estimates
     int* h_rank = nullptr;
     float* d_image = nullptr;     // [H][W][4]
     float* d_scene_depth = nullptr;
@@ -158,6 +159,7 @@ void   hl_build_grid(vp_ctx* c);                       // GridConsts + mvPos    
 void   hl_build_psys(vp_ctx* c, const float m[16]);
 void   hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p);
 int    hl_z_boundary(const vp_ctx* c, const vp_camera* cam);             //           VPR.cs:642-648
+inline int rm_num_super_tiles(int W, int H) { return ((((W + 15) / 16) + 3) / 4) * ((((H + 15) / 16) + 1) / 2); }   // 64x32 px
 void   hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank);  //           VPR.cs:613-632
 void   hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k);
 
