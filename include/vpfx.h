@@ -206,6 +206,10 @@ int  vp_raymarch_partial_device(vp_ctx* ctx, const vp_camera* cam, const vp_raym
  * d_partials[i] (device pointers, host array) are applied in the given order, kinds[i] = 0 OVER, 1 UNDER. */
 int  vp_blend_partials_device(vp_ctx* ctx, const void* const* d_partials, const int32_t* kinds, int32_t n,
                               void* d_rgba_out);
+/* The same blend over num_pixels consecutive pixels only (all pointers already point at the first of them): the blend
+ * is per pixel, so N ranks can each finish 1/N of the image after an all-to-all of the partial images' pieces. */
+int  vp_blend_partials_range_device(vp_ctx* ctx, const void* const* d_partials, const int32_t* kinds, int32_t n,
+                                    void* d_rgba_out, int64_t num_pixels);
 /* (particle, metavoxel) pairs per light-axis slice zz over the WHOLE grid (independent of the owned slab): the
  * work histogram from which callers cut balanced slabs.  Needs vp_set_frame + vp_upload_particles; invalidates bins. */
 int  vp_z_histogram(vp_ctx* ctx, int64_t* pairs_per_z /* [Nz] */);

@@ -47,11 +47,19 @@ class OracleSlabEngine:
         return torch.from_numpy(over), torch.from_numpy(under)
 
     def blend(self, images, kinds):
-        sc = self.sc
-        return torch.from_numpy(self.O.blend_partials(sc.width, sc.height, [t.numpy() for t in images], kinds))
+        npix = images[0].numel() // 4               # pieces of the image: the blend is per pixel
+        out = self.O.blend_partials(npix, 1, [np.ascontiguousarray(t.numpy()).reshape(1, npix, 4) for t in images], kinds)
+        return torch.from_numpy(out.reshape(tuple(images[0].shape)))
 
 
-def _worker(rank, world, port, cam_pos, out_path):
+def _scene(S, width):
+    sc = S.make_scene("T0")
+    if width is not None:
+        sc.width = width                       # 95 x 64 pixels do not divide by 2, 3 or 4: padded pieces
+    return sc
+
+
+def _worker(rank, world, port, cam_pos, out_path, width=None):
     sys.path.insert(0, ROOT)
     from __graft_entry__ import load_package
     load_package()
@@ -59,17 +67,21 @@ def _worker(rank, world, port, cam_pos, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sc = S.make_scene("T0")
+    sc = _scene(S, width)
     if cam_pos is not None:
         sc.set_camera(cam_pos)
     bounds = PAR.slab_bounds(sc.N[2], world)
     eng = OracleSlabEngine(sc, bounds[rank])
     pipe = PAR.SlabPipeline(eng, bounds, rank, world)
     pipe.fill(sc.fill_params())
-    img = pipe.render(sc.camera(), sc.raymarch_params())
+    img = pipe.render(sc.camera(), sc.raymarch_params())                    # assembled on rank 0
+    img_all = pipe.render(sc.camera(), sc.raymarch_params(), result="all")  # ... or everywhere
+    assert (img is None) == (rank != 0)
     lm = eng.o.read_lightmap()
     if rank == world - 1:
-        np.savez(out_path, img=img.numpy(), lightmap=lm)
+        np.savez(out_path + ".last.npz", img=img_all.numpy(), lightmap=lm)
+    if rank == 0:
+        np.savez(out_path, img=img.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,11 +94,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,cam_pos", [(2, None), (3, None), (2, (1.5, 14.0, 1.0)), (4, (1.5, 14.0, 1.0))])
-def test_slab_pipeline_matches_single_process(tmp_path, world, cam_pos):
+@pytest.mark.parametrize("world,cam_pos,width", [(2, None, None), (3, None, 95), (2, (1.5, 14.0, 1.0), None), (4, (1.5, 14.0, 1.0), 95)])
+def test_slab_pipeline_matches_single_process(tmp_path, world, cam_pos, width):
     from vpfx_amd import scene as S
     from oracle import oracle as O
-    sc = S.make_scene("T0")
+    sc = _scene(S, width)
     if cam_pos is not None:
         sc.set_camera(cam_pos)
     o = O.Oracle(sc.config())
@@ -95,7 +107,8 @@ def test_slab_pipeline_matches_single_process(tmp_path, world, cam_pos):
     o.fill(sc.fill_params())
     ref = o.raymarch(sc.camera(), sc.raymarch_params())
     out = str(tmp_path / "out.npz")
-    mp.spawn(_worker, args=(world, _free_port(), cam_pos, out), nprocs=world, join=True)
-    got = np.load(out)
+    mp.spawn(_worker, args=(world, _free_port(), cam_pos, out, width), nprocs=world, join=True)
+    got, last = np.load(out), np.load(out + ".last.npz")
     assert np.abs(got["img"] - ref).max() <= 1e-5
-    np.testing.assert_allclose(got["lightmap"], o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    assert np.array_equal(got["img"], last["img"])
+    np.testing.assert_allclose(last["lightmap"], o.read_lightmap(), rtol=1e-5, atol=1e-9)

@@ -117,6 +117,7 @@ EXPORTED_SYMBOLS = [
     "vp_set_frame", "vp_bin", "vp_upload_particles", "vp_bin_resident", "vp_fill",
     "vp_raymarch", "vp_raymarch_device", "vp_composite_device",
     "vp_fill_local", "vp_fill_finish", "vp_raymarch_partial_device", "vp_blend_partials_device",
+    "vp_blend_partials_range_device",
     "vp_z_boundary", "vp_z_histogram", "vp_set_occluders", "vp_render_light_depth", "vp_render_scene_depth",
     "vp_get_mv_positions", "vp_read_binlist", "vp_read_bincounts", "vp_read_brick",
     "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",

@@ -404,7 +404,17 @@ VP_EXPORT int vp_blend_partials_device(vp_ctx* c, const void* const* d_partials,
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_partials || !kinds || n < 0 || !d_rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_blend_partials_device: bad argument");
     int rc = ensure_device(c); if (rc) return rc;
-    return launch_blend(c, d_partials, kinds, n, (float*)d_rgba_out);
+    return launch_blend(c, d_partials, kinds, n, (float*)d_rgba_out, (size_t)c->cfg.width * c->cfg.height);
+}
+
+VP_EXPORT int vp_blend_partials_range_device(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int32_t n, void* d_rgba_out,
+                                             int64_t num_pixels)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!d_partials || !kinds || n < 0 || !d_rgba_out || num_pixels < 0)
+        return vp_fail(c, VP_ERR_BAD_ARG, "vp_blend_partials_range_device: bad argument");
+    int rc = ensure_device(c); if (rc) return rc;
+    return launch_blend(c, d_partials, kinds, n, (float*)d_rgba_out, (size_t)num_pixels);
 }
 
 VP_EXPORT int vp_composite_device(vp_ctx* c, const void* d_particles_rgba, void* d_scene_rgba)

@@ -578,13 +578,13 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
     return VP_OK;
 }
 
-int launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out)
+int launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out, size_t npix)
 {
     if (n > MAX_PARTIALS) return vp_fail(c, VP_ERR_BAD_ARG, "at most %d partial images", MAX_PARTIALS);
     BlendArgs a{};
     a.n = n;
     for (int i = 0; i < n; ++i) { a.img[i] = (const float4*)d_partials[i]; a.kind[i] = kinds[i]; }
-    const size_t npix = (size_t)c->cfg.width * c->cfg.height;
+    if (npix == 0) return VP_OK;
     hipLaunchKernelGGL(k_blend, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, a, npix, (float4*)d_out);
     VP_HIP(hipGetLastError());
     return VP_OK;

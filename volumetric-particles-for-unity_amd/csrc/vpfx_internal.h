@@ -172,7 +172,7 @@ int  launch_build_cubequads(vp_ctx* c, const float* d_cube, int S);
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
 // raymarch.hip
 int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under);
-int  launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out);
+int    launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out, size_t npix);
 int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);
 // occluders.hip
 int  launch_light_depth(vp_ctx* c, float nearz, float farz, float cam_dist, float* d_out);

@@ -154,11 +154,16 @@ class Engine:
                                                    C.byref(mask)), "vp_raymarch_partial_device")
         return mask.value
 
-    def blend_partials_device(self, d_partials, kinds, d_out: int):
+    def blend_partials_device(self, d_partials, kinds, d_out: int, num_pixels=None):
+        """Ordered blend of whole partial images, or (num_pixels given) of that many consecutive pixels."""
         n = len(d_partials)
         ptrs = (C.c_void_p * n)(*d_partials)
         k = (C.c_int32 * n)(*kinds)
-        self._ck(self.L.vp_blend_partials_device(self.h, ptrs, k, n, C.c_void_p(d_out)), "vp_blend_partials_device")
+        if num_pixels is None:
+            self._ck(self.L.vp_blend_partials_device(self.h, ptrs, k, n, C.c_void_p(d_out)), "vp_blend_partials_device")
+        else:
+            self._ck(self.L.vp_blend_partials_range_device(self.h, ptrs, k, n, C.c_void_p(d_out), C.c_int64(int(num_pixels))),
+                     "vp_blend_partials_range_device")
 
     def composite_device(self, d_particles: int, d_scene: int):
         self._ck(self.L.vp_composite_device(self.h, C.c_void_p(d_particles), C.c_void_p(d_scene)), "vp_composite_device")

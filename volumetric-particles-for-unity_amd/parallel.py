@@ -8,9 +8,13 @@ exactly two cross-slab dependencies, and each becomes ONE collective (RCCL over 
             so every rank fills its slab with T_in = 1, publishing the slab's transmittance map tau
             (all_gather, (Ny*nv)*(Nx*nv)*4 B per rank), then finishes with T_in = prod_{slabs nearer the light} tau.
   raymarch  inter-metavoxel blending (VPR.cs:652-711).  The draw order is zz-major in both phases, so a slab's
-            MVs are contiguous in it: each rank composites its slab into a premultiplied partial image
-            (all_gather, W*H*16 B per rank) and every rank applies the ordered OVER/UNDER blend of the partials.
-            Only the one slab that straddles zBoundary has two partials; its second image is broadcast.
+            MVs are contiguous in it: each rank composites its slab into a premultiplied partial image.  The
+            ordered OVER/UNDER blend of the partials is per pixel, so it is sharded too: ONE all-to-all hands
+            rank r the r-th piece (1/N of the pixels) of every partial image, rank r blends its piece, and the
+            finished pieces are gathered on the display rank (rank 0) -- (N-1)/N * W*H*16 B sent and received
+            per rank instead of (N-1) * W*H*16 B for an all-gather of whole images (xGMI is point to point:
+            the all-to-all uses all seven links of a GPU at once).  Only the one slab that straddles zBoundary
+            has two partials; the pieces of its second image are scattered.
 
 The compute engine is injected: `HipSlabEngine` (libvpfx, device tensors) in production; the tests drive the same
 pipeline with a CPU engine to check the sharding math without a GPU.
@@ -71,7 +75,8 @@ class SlabPipeline:
     """bin -> fill -> raymarch of one frame across the ranks of `group`.
 
     `engine` must provide: bin_resident(); fill_local(params) -> tau tensor; fill_finish(T_in tensor | None);
-    raymarch_partial(cam, rp) -> (over, under) tensors; blend(images, kinds) -> tensor; z_boundary(cam).
+    raymarch_partial(cam, rp) -> (over, under) [H, W, 4] tensors; blend(images, kinds) -> tensor, for equally shaped
+    [pixels, 4] pieces; z_boundary(cam).
     """
 
     def __init__(self, engine, bounds, rank: int, world: int, group=None):
@@ -79,6 +84,9 @@ class SlabPipeline:
         self._tau_all = None       # [world, LH, LW] receive buffer of the transmittance all-gather
         self._img_all = None       # [world, H, W, 4] receive buffer of the partial-image all-gather
         self._second = None
+        self._final = None
+        self._pad = {}
+        self._stage = None         # gloo + device tensors: stage the image exchange through host memory
         self._into_tensor = True   # all_gather_into_tensor (one contiguous receive buffer, no per-rank copies) if supported
 
     def _all_gather(self, buf, src):
@@ -107,7 +115,57 @@ class SlabPipeline:
             t_in = taus[r].clone() if t_in is None else t_in.mul_(taus[r])
         self.eng.fill_finish(t_in)
 
-    def render(self, cam, rp):
+    # -- collectives of the image exchange.  RCCL ("nccl") takes device tensors directly; under gloo (functional tests, several
+    #    ranks sharing one GPU) device tensors are staged through host memory, since gloo only moves host buffers for these ops.
+    def _staged(self, t):
+        if self._stage is None:
+            self._stage = dist.get_backend(self.group) == "gloo"
+        return self._stage and t.is_cuda
+
+    def _all_to_all(self, out, inp):
+        if self._staged(inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o.view(-1), inp.reshape(-1).cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out.view(-1), inp.reshape(-1), group=self.group)
+
+    def _scatter(self, out, chunks, src):
+        if self._staged(out):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.scatter(o, None if chunks is None else [c.cpu() for c in chunks], src=src, group=self.group)
+            out.copy_(o)
+        else:
+            dist.scatter(out, None if chunks is None else [c.contiguous() for c in chunks], src=src, group=self.group)
+
+    def _gather_to(self, final, mine, dst, everywhere):
+        """final [world, piece, 4] <- every rank's finished piece, on rank dst (or on all ranks)."""
+        staged = self._staged(mine)
+        src = mine.cpu() if staged else mine
+        buf = torch.empty(final.shape, dtype=final.dtype) if staged else final
+        if everywhere:
+            dist.all_gather_into_tensor(buf.view(-1), src.reshape(-1), group=self.group)
+        else:
+            dist.gather(src, list(buf.unbind(0)) if self.rank == dst else None, dst=dst, group=self.group)
+        if staged and (everywhere or self.rank == dst):
+            final.copy_(buf)
+
+    def _pieces(self, img, tag):
+        """[world, piece, 4] view of an [H, W, 4] image, zero-padded up to world * piece pixels (copy only if padding is needed)."""
+        npix = img.shape[0] * img.shape[1]
+        piece = -(-npix // self.world)
+        flat = img.reshape(npix, 4)
+        if piece * self.world != npix:
+            buf = self._pad.get(tag)
+            if buf is None:
+                buf = self._pad[tag] = torch.zeros((piece * self.world, 4), dtype=img.dtype, device=img.device)
+            buf[:npix].copy_(flat)
+            flat = buf
+        return flat.view(self.world, piece, 4), npix, piece
+
+    def render(self, cam, rp, result="rank0"):
+        """One frame's image.  result = "rank0": the finished image is assembled on rank 0 only (the display GPU; other
+        ranks return None); "all": on every rank."""
         if self.world == 1:
             return self.eng.raymarch(cam, rp)
         zb = self.eng.z_boundary(cam)
@@ -115,23 +173,26 @@ class SlabPipeline:
         over, under = self.eng.raymarch_partial(cam, rp)
         z0, z1 = self.bounds[self.rank]
         primary = over if z0 <= zb else under      # the straddler's primary is its OVER image
+        send, npix, piece = self._pieces(primary, "primary")
         if self._img_all is None:
-            self._img_all = torch.empty((self.world,) + tuple(primary.shape), dtype=primary.dtype, device=primary.device)
-        prim = self._all_gather(self._img_all, primary)
-        second = None
+            self._img_all = torch.empty_like(send)                     # [world, piece, 4]: piece `rank` of every rank's primary image
+            self._second = torch.empty_like(send[0])
+            self._final = torch.empty_like(send)                       # the assembled image (padded)
+        self._all_to_all(self._img_all, send)
         if straddler is not None:
+            chunks = None
             if self.rank == straddler:
-                second = under
-            else:
-                if self._second is None:
-                    self._second = torch.empty_like(under)
-                second = self._second
-            dist.broadcast(second, src=straddler, group=self.group)
+                chunks = list(self._pieces(under, "second")[0].unbind(0))
+            self._scatter(self._second, chunks, straddler)
         images, kinds = [], []
         for r, which, kind in plan:
-            images.append(second if (r == straddler and which == "under") else prim[r])
+            images.append(self._second if (r == straddler and which == "under") else self._img_all[r])
             kinds.append(kind)
-        return self.eng.blend(images, kinds)
+        mine = self.eng.blend(images, kinds)                           # [piece, 4]
+        self._gather_to(self._final, mine, 0, result == "all")
+        if result != "all" and self.rank != 0:
+            return None
+        return self._final.view(-1, 4)[:npix].view(primary.shape)
 
 
 class HipSlabEngine:
@@ -145,6 +206,7 @@ class HipSlabEngine:
         self._over = torch.empty(self.img_shape, dtype=torch.float32, device=device)
         self._under = torch.empty(self.img_shape, dtype=torch.float32, device=device)
         self._out = torch.empty(self.img_shape, dtype=torch.float32, device=device)
+        self._piece_out = None
 
     def bin_resident(self):
         self.e.bin_resident()
@@ -171,5 +233,10 @@ class HipSlabEngine:
         return self._over, self._under
 
     def blend(self, images, kinds):
-        self.e.blend_partials_device([t.data_ptr() for t in images], kinds, self._out.data_ptr())
-        return self._out
+        """Ordered blend of equally shaped [pixels, 4] pieces (or whole [H, W, 4] images)."""
+        shape = tuple(images[0].shape)
+        if self._piece_out is None or tuple(self._piece_out.shape) != shape:
+            self._piece_out = torch.empty(shape, dtype=torch.float32, device=self.dev)
+        npix = self._piece_out.numel() // 4
+        self.e.blend_partials_device([t.data_ptr() for t in images], kinds, self._piece_out.data_ptr(), num_pixels=npix)
+        return self._piece_out
