@@ -73,7 +73,7 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
         if (S != c->cubeS) {
             if (c->d_cubequads) VP_HIP(hipFree(c->d_cubequads));
             c->d_cubequads = nullptr;
-            VP_HIP(hipMalloc((void**)&c->d_cubequads, (size_t)6 * (S + 1) * (S + 1) * sizeof(float4)));
+            VP_HIP(hipMalloc((void**)&c->d_cubequads, (size_t)6 * (S + 1) * (S + 2) * sizeof(float2) + 16));
             c->cubeS = S;
         }
         float* d_cube = nullptr;

@@ -112,7 +112,7 @@ struct vp_ctx {
     float2* d_dens_ao = nullptr;  // split-fill scratch [brick_cap][nv^3]
     size_t dens_cap = 0;
     float* d_lightmap = nullptr;  // [(Ny*nv)][(Nx*nv)]
-    float4* d_cubequads = nullptr;// [6][(S+1)][(S+1)] bilinear footprints (t00, t01, t10, t11)
+    float4* d_cubequads = nullptr;// footprint table: float2 column pairs [6][S+1][S+2] (see k_build_cubequads)
     int cubeS = 0;
     float* d_depthmap = nullptr;
     bool have_depthmap = false;
