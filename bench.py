@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--share-gpu", action="store_true", help="functional test only: all ranks on cuda:0")
+    ap.add_argument("--exchange", default="tiles", choices=["tiles", "all_gather"],
+                    help="N > 1 image exchange: all-to-all of screen pieces + sharded blend (default) or one all-gather of whole partial images")
     ap.add_argument("--uniform-slabs", action="store_true", help="equal-thickness slabs instead of pair-count balanced ones")
     args = ap.parse_args()
 
@@ -115,7 +117,7 @@ def main():
     eng = E.Engine(sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0)))
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
-    pipe = PAR.SlabPipeline(PAR.HipSlabEngine(eng, device), bounds, rank, world)
+    pipe = PAR.SlabPipeline(PAR.HipSlabEngine(eng, device), bounds, rank, world, exchange=args.exchange)
     fp_first, fp = sc.fill_params(), sc.fill_params()
     fp.cubemap = None                                                           # cubemap stays resident after the first fill
     cam, rp = sc.camera(), sc.raymarch_params()
@@ -192,7 +194,7 @@ def main():
             "dtype": "f32 compute / f16 voxel storage", "data": "synthetic",
             "config": {"workload": f"{args.config}: {sc.N[0]}x{sc.N[1]}x{sc.N[2]} metavoxels x {nv}^3 voxels, "
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
-                       "parallelism": f"zslab{world}", "slabs": bounds if world > 1 else None,
+                       "parallelism": f"zslab{world}" + (f" ({args.exchange} exchange)" if world > 1 else ""), "slabs": bounds if world > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),
                        "work_unit": "voxels + executed samples of the 1-GPU job (fixed for every N)",

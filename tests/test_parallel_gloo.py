@@ -76,6 +76,8 @@ def _worker(rank, world, port, cam_pos, out_path, width=None):
     pipe.fill(sc.fill_params())
     img = pipe.render(sc.camera(), sc.raymarch_params())                    # assembled on rank 0
     img_all = pipe.render(sc.camera(), sc.raymarch_params(), result="all")  # ... or everywhere
+    whole = PAR.SlabPipeline(eng, bounds, rank, world, exchange="all_gather").render(sc.camera(), sc.raymarch_params())
+    assert np.array_equal(whole.numpy(), img_all.numpy())                   # one all-gather of whole partial images
     assert (img is None) == (rank != 0)
     lm = eng.o.read_lightmap()
     if rank == world - 1:

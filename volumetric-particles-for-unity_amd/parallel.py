@@ -79,8 +79,14 @@ class SlabPipeline:
     [pixels, 4] pieces; z_boundary(cam).
     """
 
-    def __init__(self, engine, bounds, rank: int, world: int, group=None):
+    def __init__(self, engine, bounds, rank: int, world: int, group=None, exchange: str = "tiles"):
+        """exchange = "tiles": all-to-all of image pieces, sharded final blend, gather (default, least xGMI traffic);
+        "all_gather": ONE all-gather of whole partial images, every rank blends the full image (SURVEY.md 8(e) first form)."""
+        if exchange not in ("tiles", "all_gather"):
+            raise ValueError(f"exchange = {exchange!r}")
         self.eng, self.bounds, self.rank, self.world, self.group = engine, list(bounds), rank, world, group
+        self.exchange = exchange
+        self._whole_all = None     # [world, H, W, 4] receive buffer of the whole-image all-gather
         self._tau_all = None       # [world, LH, LW] receive buffer of the transmittance all-gather
         self._img_all = None       # [world, H, W, 4] receive buffer of the partial-image all-gather
         self._second = None
@@ -173,6 +179,17 @@ class SlabPipeline:
         over, under = self.eng.raymarch_partial(cam, rp)
         z0, z1 = self.bounds[self.rank]
         primary = over if z0 <= zb else under      # the straddler's primary is its OVER image
+        if self.exchange == "all_gather":
+            if self._whole_all is None:
+                self._whole_all = torch.empty((self.world,) + tuple(primary.shape), dtype=primary.dtype, device=primary.device)
+                self._whole_second = torch.empty_like(under)
+            prim = self._all_gather(self._whole_all, primary)
+            second = None
+            if straddler is not None:
+                second = under if self.rank == straddler else self._whole_second
+                dist.broadcast(second, src=straddler, group=self.group)
+            images = [second if (r == straddler and which == "under") else prim[r] for r, which, kind in plan]
+            return self.eng.blend(images, [kind for _, _, kind in plan])
         send, npix, piece = self._pieces(primary, "primary")
         if self._img_all is None:
             self._img_all = torch.empty_like(send)                     # [world, piece, 4]: piece `rank` of every rank's primary image
