@@ -102,13 +102,14 @@ def main():
     bounds = PAR.slab_bounds(sc.N[2], world, weights)
     # strong scaling: the unit of work is the SINGLE-GPU job (its voxels and its executed samples).  Sharded runs execute
     # more lattice samples in total (the saturation early-out only sees one slab), which must not inflate `value`.
-    ref_units = None
+    ref_units, ref_image = None, None
     if world > 1 and rank == 0:
         one = E.Engine(sc.config(device=local_rank))
         one.set_frame(sc.light_to_world, sc.grid_center)
         one.bin(sc.particles, sc.layout, sc.psys_local_to_world)
         one.fill(sc.fill_params())
-        one.raymarch_device(sc.camera(), sc.raymarch_params(), torch.empty((sc.height, sc.width, 4), device=device).data_ptr())
+        ref_image = torch.empty((sc.height, sc.width, 4), device=device)
+        one.raymarch_device(sc.camera(), sc.raymarch_params(), ref_image.data_ptr())
         one.sync()
         st1 = one.stats()
         ref_units = (st1["voxels_filled"], st1["samples"])
@@ -137,8 +138,9 @@ def main():
     barrier()
     k_fill, k_rm, k_bin, k_fin = [], [], [], []
     t0 = time.perf_counter()
+    image = None
     for _ in range(args.steps):
-        step()
+        image = step()
         # HIP-event durations of the dominant kernels, recorded on the stream they were launched on
         k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))
         if world > 1:
@@ -185,6 +187,8 @@ def main():
         executed = (voxels, samples)
         if ref_units is not None:
             voxels, samples = float(ref_units[0]), float(ref_units[1])
+        # N > 1: the sharded frame against the single-GPU frame rendered on this rank before the timed region
+        shard_err = float((image - ref_image).abs().max().item()) if (ref_image is not None and image is not None) else None
         out = {
             "metric": "Mvoxels/s filled + Msamples/s raymarched, 32^3x32^3 grid @1080p",
             "value": (voxels + samples) / (dt / args.steps) / 1e6,
@@ -198,7 +202,8 @@ def main():
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),
                        "work_unit": "voxels + executed samples of the 1-GPU job (fixed for every N)",
-                       "samples_executed_all_ranks": int(executed[1])},
+                       "samples_executed_all_ranks": int(executed[1]),
+                       "max_abs_rgba_diff_vs_1gpu_frame": shard_err},
             "fill_mvoxels_per_s": voxels / (fill_ms * 1e-3) / 1e6 if world == 1 else None,
             "raymarch_msamples_per_s": samples / (rm_ms * 1e-3) / 1e6 if world == 1 else None,
             "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms,
