@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $CMD > $OUT/pm
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- $CMD > $OUT/pmc4.log 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum -d $OUT/pmc5 -o pmc5 -- $CMD > $OUT/pmc5.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $OUT/kt/kt_results.db $OUT/pmc1/pmc1_results.db $OUT/pmc2/pmc2_results.db $OUT/pmc3/pmc3_results.db $OUT/pmc4/pmc4_results.db $OUT/pmc5/pmc5_results.db > $OUT/summary.txt 2>&1
-tail -1 $OUT/kt_bench.log > $OUT/bench_line.json
+grep -h "^{\"metric\"" $OUT/kt_bench.log | tail -1 > $OUT/bench_line.json
 python $GRAFT_REPO_ROOT/scripts/traffic_json.py $OUT/pmc3/pmc3_results.db $OUT/pmc4/pmc4_results.db $OUT/traffic_C3.json
 rm -rf $OUT/*/*.db
 cat $OUT/summary.txt | grep -E '==|k_fill|k_raymarch|kernel' | head -70
