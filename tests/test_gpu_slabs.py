@@ -44,6 +44,13 @@ def run_slabs(sc, world, cam_pos=None, weights=None):
     imgs = [parts[(r, which)] for r, which, _ in plan]
     kinds = [k for _, _, k in plan]
     out = engs[0].blend(imgs, kinds).cpu().numpy()
+    # the sharded form of the same blend (vp_blend_partials_range_device): pieces of 1/world of the pixels, then reassembled
+    npix = sc.width * sc.height
+    piece = -(-npix // world)
+    flat = [torch.cat([t.reshape(npix, 4), torch.zeros((piece * world - npix, 4), device=dev)]) for t in imgs]
+    pieces = [engs[r % len(engs)].blend([f[r * piece:(r + 1) * piece] for f in flat], kinds).clone() for r in range(world)]
+    sharded = torch.cat(pieces)[:npix].reshape(sc.height, sc.width, 4).cpu().numpy()
+    assert np.array_equal(sharded, out)
     lightmap = engs[-1].e.read_lightmap()
     return out, lightmap, bounds, zb, straddler, engs
 
