@@ -25,3 +25,19 @@ for _ in range(n):
     img = e.raymarch(cam, rp)
 tr = (time.perf_counter() - t0) / n
 print(f"vp_bin (H2D {sc.particles.nbytes/1e6:.1f} MB + bin) {tb*1e3:.3f} ms; vp_raymarch (+ D2H {img.nbytes/1e6:.1f} MB) {tr*1e3:.3f} ms")
+# the same with the two per-frame host buffers page-locked (vp_pin_host_buffer)
+import numpy as np
+out = np.empty_like(img)
+e.pin(out); e.pin(sc.particles)
+e.raymarch(cam, rp, out=out)
+t0 = time.perf_counter()
+for _ in range(n):
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp); e.raymarch(cam, rp, out=out)
+dtp = (time.perf_counter() - t0) / n
+t0 = time.perf_counter()
+for _ in range(n):
+    e.raymarch(cam, rp, out=out)
+trp = (time.perf_counter() - t0) / n
+assert np.array_equal(out, img)
+print(f"pinned host buffers: step {dtp*1e3:.3f} ms -> {(st['voxels_filled']+st['samples'])/dtp/1e6:.0f} M(voxels+samples)/s; vp_raymarch (+ D2H) {trp*1e3:.3f} ms")
+e.unpin(out); e.unpin(sc.particles)

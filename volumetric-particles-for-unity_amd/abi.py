@@ -113,7 +113,7 @@ class vp_stats(C.Structure):
 
 # every symbol include/vpfx.h declares (checked by tests/test_abi.py against the built library)
 EXPORTED_SYMBOLS = [
-    "vp_create", "vp_destroy", "vp_last_error", "vp_abi_version", "vp_set_stream", "vp_sync",
+    "vp_create", "vp_destroy", "vp_last_error", "vp_abi_version", "vp_set_stream", "vp_sync", "vp_pin_host_buffer", "vp_unpin_host_buffer",
     "vp_set_frame", "vp_bin", "vp_upload_particles", "vp_bin_resident", "vp_fill",
     "vp_raymarch", "vp_raymarch_device", "vp_composite_device",
     "vp_fill_local", "vp_fill_finish", "vp_raymarch_partial_device", "vp_blend_partials_device",

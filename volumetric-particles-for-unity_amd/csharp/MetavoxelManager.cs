@@ -81,12 +81,15 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_bin(IntPtr ctx, IntPtr particles, int count, ref vp_particle_layout layout, float[] psysLocalToWorld);
         [DllImport(LIB)] static extern int vp_fill(IntPtr ctx, ref vp_fill_params p);
         [DllImport(LIB)] static extern int vp_raymarch(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, IntPtr rgbaOut);
+        [DllImport(LIB)] static extern int vp_pin_host_buffer(IntPtr ctx, IntPtr ptr, ulong bytes);
+        [DllImport(LIB)] static extern int vp_unpin_host_buffer(IntPtr ctx, IntPtr ptr);
 
         IntPtr ctx = IntPtr.Zero;
         ParticleSystem.Particle[] parts;
         float[] cubemapR;              // .x channel of the displacement cubemap, faces +X,-X,+Y,-Y,+Z,-Z, row 0 = top
         bool cubemapResident = false;
         float[] rgba;                  // particlesRT as float RGBA (premultiplied), row 0 = bottom
+        GCHandle rgbaHandle;           // pinned for the component's lifetime (vp_pin_host_buffer)
         Texture2D particlesTex;
         Quaternion lightOrientation;
         Vector3 wsGridCenter;
@@ -114,6 +117,9 @@ namespace MetavoxelEngine
             if (rc != 0) { Debug.LogError("vp_create failed (" + rc + "): " + Marshal.PtrToStringAnsi(vp_last_error(IntPtr.Zero))); return; }
             parts = new ParticleSystem.Particle[particleSys.maxParticles];
             rgba = new float[Screen.width * Screen.height * 4];
+            // the read-back target lives as long as the component: pin it once and page-lock it for DMA-speed copies
+            rgbaHandle = GCHandle.Alloc(rgba, GCHandleType.Pinned);
+            vp_pin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject(), (ulong)rgba.Length * 4);   // speed hint only: failure is harmless
             particlesTex = new Texture2D(Screen.width, Screen.height, TextureFormat.RGBAFloat, false);
             int S = displacementTexture.width;
             cubemapR = new float[6 * S * S];
@@ -129,7 +135,12 @@ namespace MetavoxelEngine
             UpdateMetavoxelPositions();
         }
 
-        void OnDestroy() { if (ctx != IntPtr.Zero) { vp_destroy(ctx); ctx = IntPtr.Zero; } }
+        void OnDestroy()
+        {
+            if (ctx == IntPtr.Zero) return;
+            if (rgbaHandle.IsAllocated) { vp_unpin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject()); rgbaHandle.Free(); }
+            vp_destroy(ctx); ctx = IntPtr.Zero;
+        }
 
         void OnPostRender()                                                // VPR.cs:181-220
         {
@@ -195,9 +206,7 @@ namespace MetavoxelEngine
                 px = cp.x, py = cp.y, pz = cp.z, fov_y = Mathf.Deg2Rad * c.fieldOfView, near_clip = c.nearClipPlane, far_clip = c.farClipPlane };
             var rp = new vp_raymarch_params { steps_per_mv = rayMarchSteps, soft_distance = softParticleStepDistance,
                                               scene_depth = IntPtr.Zero, flags = 0, reserved = new int[3] };
-            GCHandle h = GCHandle.Alloc(rgba, GCHandleType.Pinned);
-            try { Check(vp_raymarch(ctx, ref cam, ref rp, h.AddrOfPinnedObject()), "vp_raymarch"); }
-            finally { h.Free(); }
+            Check(vp_raymarch(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch");
             particlesTex.SetPixelData(rgba, 0);
             particlesTex.Apply(false);
         }

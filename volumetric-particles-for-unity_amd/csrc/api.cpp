@@ -212,6 +212,25 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
     delete c;
 }
 
+VP_EXPORT int vp_pin_host_buffer(vp_ctx* c, void* ptr, uint64_t bytes)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!ptr || !bytes) return vp_fail(c, VP_ERR_BAD_ARG, "vp_pin_host_buffer: null buffer");
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_unpin_host_buffer(vp_ctx* c, void* ptr)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!ptr) return vp_fail(c, VP_ERR_BAD_ARG, "vp_unpin_host_buffer: null buffer");
+    int rc = ensure_device(c); if (rc) return rc;
+    if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    VP_HIP(hipHostUnregister(ptr));
+    return VP_OK;
+}
+
 VP_EXPORT int vp_set_stream(vp_ctx* c, void* hip_stream)
 {
     if (!c) return VP_ERR_BAD_ARG;

@@ -84,6 +84,13 @@ class Engine:
     def sync(self):
         self._ck(self.L.vp_sync(self.h), "vp_sync")
 
+    def pin(self, array: np.ndarray):
+        """Page-lock a numpy buffer passed to bin()/raymarch(out=...) every frame (speed hint; keep `array` alive until unpin)."""
+        self._ck(self.L.vp_pin_host_buffer(self.h, _vp(array), C.c_uint64(array.nbytes)), "vp_pin_host_buffer")
+
+    def unpin(self, array: np.ndarray):
+        self._ck(self.L.vp_unpin_host_buffer(self.h, _vp(array)), "vp_unpin_host_buffer")
+
     # -- frame / bin ---------------------------------------------------------------------------------
     def set_frame(self, light_to_world, grid_center):
         l = np.ascontiguousarray(light_to_world, dtype=np.float32)
@@ -140,8 +147,10 @@ class Engine:
         return out
 
     # -- ray-march -----------------------------------------------------------------------------------
-    def raymarch(self, cam, rp):
-        img = np.empty((self.H, self.W, 4), dtype=np.float32)
+    def raymarch(self, cam, rp, out=None):
+        img = np.empty((self.H, self.W, 4), dtype=np.float32) if out is None else out
+        if img.shape != (self.H, self.W, 4) or img.dtype != np.float32 or not img.flags.c_contiguous:
+            raise ValueError("raymarch(out=...): float32 C-contiguous [H, W, 4] expected")
         self._ck(self.L.vp_raymarch(self.h, C.byref(cam), C.byref(rp), _vp(img)), "vp_raymarch")
         return img
 
