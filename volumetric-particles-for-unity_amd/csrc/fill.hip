@@ -102,29 +102,39 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     const float sc = __builtin_amdgcn_cubesc(psx, psy, psz);
     const float tc = __builtin_amdgcn_cubetc(psx, psy, psz);
     const float ma2 = fabsf(__builtin_amdgcn_cubema(psx, psy, psz));   // 2 |major|
-    // u/2 = sc / (2|major|): scaling by two is exact, so fma(u/2, S, S/2 - 0.5) == fma(u, S/2, S/2 - 0.5) bit for bit
-    float uh = 0.f, vh = 0.f;
-    if (ma2 > 0.f) { const float inv = fdiv<EXACT>(1.0f, ma2); uh = sc * inv; vh = tc * inv; }
     const float Sf = f.half_s + f.half_s;
-    const float fx = fmaf(uh, Sf, f.half_s_m05), fy = fmaf(vh, Sf, f.half_s_m05);
+    float fx, fy;
+    if (EXACT) {
+        // u/2 = sc / (2|major|): scaling by two is exact, so fma(u/2, S, S/2 - 0.5) == fma(u, S/2, S/2 - 0.5) bit for bit
+        float uh = 0.f, vh = 0.f;
+        if (ma2 > 0.f) { const float inv = 1.0f / ma2; uh = sc * inv; vh = tc * inv; }
+        fx = fmaf(uh, Sf, f.half_s_m05); fy = fmaf(vh, Sf, f.half_s_m05);
+    } else {
+        // fast path: S / (2|major|) once (for the zero vector the clamp turns 1/0 into a finite number, sc = tc = 0 then
+        // give the face centre like the EXACT branch), one FMA per axis
+        const float invS = Sf * fminf(__builtin_amdgcn_rcpf(ma2), 3.0e38f);
+        fx = fmaf(sc, invS, f.half_s_m05); fy = fmaf(tc, invS, f.half_s_m05);
+    }
     const float x0 = floorf(fx), y0 = floorf(fy);
     // EXACT keeps the oracle's fx - floor(fx); the fast path uses v_fract_f32 (identical except that a weight that
     // would round up to exactly 1.0 is returned as the largest float below 1)
     tx = EXACT ? fx - x0 : __builtin_amdgcn_fractf(fx);
     ty = EXACT ? fy - y0 : __builtin_amdgcn_fractf(fy);
     // |sc|, |tc| <= |major|, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
-    // the clamp-addressing of the footprint table never needs a min/max here.  The index of the column pair
-    // (face*(S+1) + y0+1)*(S+2) + x0+1 is formed in float (exact: all values are small integers), one conversion.
-    return (unsigned)fmaf(fmaf(fid, Sf + 1.0f, y0 + 1.0f), Sf + 2.0f, x0 + 1.0f);
+    // the clamp-addressing of the footprint table never needs a min/max here.  The BYTE offset of the column pair,
+    // 8 ((face (S+1) + y0 + 1)(S+2) + x0 + 1), is formed in float as three FMAs (exact: small integers) + one conversion.
+    const float S2f = Sf + 2.0f;
+    return (unsigned)fmaf(fid, 8.0f * ((Sf + 1.0f) * S2f), fmaf(y0, 8.0f * S2f, fmaf(x0, 8.0f, 8.0f * (S2f + 1.0f))));
 }
 
 template <bool EXACT>
-__device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
+__device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
+                                           const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
                                            float d2, float opw, float& den, float& net)
 {
     const float a = fmaf(tx, q.z - q.x, q.x), b = fmaf(tx, q.w - q.y, q.y);
     const float raw = fmaf(ty, b - a, a);
-    net = fmaf(f.D, raw, f.one_minus_D);                                          // netDisplacement   :119
+    net = fmaf(f.D, raw, one_minus_D);                                            // netDisplacement   :119
     float t;
     if (EXACT) {
         const float d2q = 4.0f * d2;                                              // dot(2ps, 2ps)     :121
@@ -134,9 +144,15 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, const float4 q /
         // same quantity, (4 d2 - net) / (-0.3 net) = 10/3 - (40/3) d2 / net, as reciprocal + multiply + fused clamp
         t = __builtin_amdgcn_fmed3f(fmaf(d2 * __builtin_amdgcn_rcpf(net), -13.333333f, 3.3333333f), 0.f, 1.f);
     }
-    const float base = (t * t) * (3.0f - 2.0f * t);
-    // :127, :130-131.  opw = 1.0 exactly when _FadeOutParticles is off; the fast path folds the two factors (one rounding less)
-    den = EXACT ? (base * f.opacity_factor) * opw : base * (f.opacity_factor * opw);
+    // :126-127, :130-131: t*t*(3 - 2t) * opacityFactor * (fade ? opacity : 1).  opw = 1.0 exactly when _FadeOutParticles is off.
+    // The fast path folds the wave-uniform factors into the cubic's coefficients (t*t) * (3k - 2k t), k = opacityFactor * opw.
+    if (EXACT) {
+        const float base = (t * t) * (3.0f - 2.0f * t);
+        den = (base * f.opacity_factor) * opw;
+    } else {
+        const float k = f.opacity_factor * opw;
+        den = (t * t) * fmaf(t, -2.0f * k, 3.0f * k);
+    }
 }
 
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
@@ -167,6 +183,8 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
     const float lsSceneDepth = (dm - f.bq) * f.inv_a;                                    // :218-219
 
     float prop = (MODE == 0 && p_light_in) ? p_light_in[lmi] : 1.0f;                     // GL.Clear(Color.red) VPR.cs:499
+    float one_minus_D = f.one_minus_D;
+    asm volatile("" : "+v"(one_minus_D));                                                // keep it in a VGPR (see cube_shade)
 
     for (int zz = g.z0; zz < g.z1; ++zz) {                                               // z-major = draw order VPR.cs:505
         const int mi = (zz * g.Ny + yy) * g.Nx + xx;
@@ -265,13 +283,13 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                     d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
                     hit = d2 <= 0.25f;                                                   // Fill.shader:172,196
                     const unsigned qi = cube_address<EXACT>(f, psx, psy, psz, tx, ty);
-                    const unsigned off = hit ? qi * 8u : 0u;
+                    const unsigned off = hit ? qi : 0u;                                  // byte offset into the footprint table
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
                 };
                 auto stage2 = [&](int s, float tx, float ty, float d2, bool hit, const f32x4& q) {
                     if (hit) {
                         float den, net;
-                        cube_shade<EXACT>(f, make_float4(q[0], q[1], q[2], q[3]), tx, ty, d2, opacity, den, net);
+                        cube_shade<EXACT>(f, one_minus_D, make_float4(q[0], q[1], q[2], q[3]), tx, ty, d2, opacity, den, net);
                         dens[s] += den;                                                  // :200
                         // ao = max(ao, net) (:201); both are >= 0, so the max of the bit patterns is the float max
                         ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
