@@ -242,8 +242,9 @@ k_tile_cost(RmConsts k, const int* __restrict__ brick_index, int sgx, float* __r
 {
     __shared__ float part[4];
     const int sti = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float colf = fminf((float)((sti % sgx) * 64 + 16 + 32 * (wave & 1)), (float)k.W - 1.f);
-    const float rowf = fminf((float)((sti / sgx) * 32 + 8 + 16 * (wave >> 1)), (float)k.H - 1.f);
+    constexpr int SW = 16 << VPFX_RM_LX, SH = 16 << VPFX_RM_LY;                    // super-tile size in pixels
+    const float colf = fminf((float)((sti % sgx) * SW + SW / 4 + (SW / 2) * (wave & 1)), (float)k.W - 1.f);
+    const float rowf = fminf((float)((sti / sgx) * SH + SH / 4 + (SH / 2) * (wave >> 1)), (float)k.H - 1.f);
     float dx = (2.0f * (colf + 0.5f) / (float)k.W) - 1.0f;
     const float dy = (2.0f * (rowf + 0.5f) / (float)k.H) - 1.0f;
     dx *= k.aspect;
@@ -314,40 +315,30 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 // owned slab composite into two separate images (multi-GPU partial images).
 // FLAGS = false compiles the vp_raymarch_params.flags paths (UNORM8 emulation, debug views) out of the hot loop.
 // One wave per workgroup (no LDS, no barriers: a finished wave frees its slot at once), five waves per SIMD.
-#ifndef VPFX_RM_WG
-#define VPFX_RM_WG 64
-#endif
 #ifndef VPFX_RM_WAVES
 #define VPFX_RM_WAVES 5
 #endif
-#define VPFX_RM_LB __launch_bounds__(VPFX_RM_WG, VPFX_RM_WAVES)
+#define VPFX_RM_LB __launch_bounds__(64, VPFX_RM_WAVES)
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
 __global__ void VPFX_RM_LB
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
 {
-#if VPFX_RM_WG == 256
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#else
-    const int wave = (int)(blockIdx.x >> 3) & 3, lane = threadIdx.x;
-#endif
+    const int lane = threadIdx.x;
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
-    // has its own L2.  Screen tiles are grouped into 4x2 super-tiles (64x32 px, about one brick's footprint); super-tile
-    // i is rendered entirely by XCD i % 8, so a brick is pulled into ~2-4 L2s instead of all eight, while neighbouring
-    // super-tiles still alternate XCDs (load balance across the image).
+    // has its own L2.  Screen tiles are grouped into super-tiles (64x32 px, about one brick's footprint); a super-tile is
+    // rendered entirely by one XCD, so a brick is pulled into ~2-4 L2s instead of all eight, while consecutive super-tiles
+    // of the dispatch order (cost-sorted, see k_tile_cost) alternate XCDs (load balance).
+    constexpr int LX = VPFX_RM_LX, LY = VPFX_RM_LY, WPS = 4 << (LX + LY);            // waves per super-tile
     const int tgx = (k.W + 15) >> 4, tgy = (k.H + 15) >> 4;
-    const int sgx = (tgx + 3) >> 2, sgy = (tgy + 1) >> 1;
-#if VPFX_RM_WG == 256
+    const int sgx = (tgx + (1 << LX) - 1) >> LX, sgy = (tgy + (1 << LY) - 1) >> LY;
     const int q = (int)(blockIdx.x >> 3);
-#else
-    const int q = (int)(blockIdx.x >> 5);
-#endif
-    const int slot = (q >> 3) * 8 + (int)(blockIdx.x & 7u);       // position in the dispatch order
-    const int j = q & 7;                                          // tile inside the super-tile
+    const int within = q % WPS, wave = within & 3, j = within >> 2;                // tile j of the super-tile, wave of the tile
+    const int slot = (q / WPS) * 8 + (int)(blockIdx.x & 7u);                       // position in the dispatch order
     if (slot >= sgx * sgy) return;
-    const int sti = tile_order ? tile_order[slot] : slot;         // super-tile index
-    const int ttx = (sti % sgx) * 4 + (j & 3), tty = (sti / sgx) * 2 + (j >> 2);
+    const int sti = tile_order ? tile_order[slot] : slot;                          // super-tile index
+    const int ttx = ((sti % sgx) << LX) + (j & ((1 << LX) - 1)), tty = ((sti / sgx) << LY) + (j >> LX);
     if (ttx >= tgx || tty >= tgy) return;
     const int col = ttx * 16 + (wave & 1) * 8 + (lane & 7);
     const int row = tty * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -516,12 +507,12 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
 #ifndef VPFX_RM_NO_ORDER
     if (nsuper <= RM_ORDER_MAX) {
         float* cost = reinterpret_cast<float*>(c->d_tile_order + nsuper + 8);
-        hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, (((k.W + 15) / 16) + 3) / 4, cost);
+        hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, rm_super_tiles_x(k.W), cost);
         hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
         order = c->d_tile_order;
     }
 #endif
-    const dim3 grid(((nsuper + 7) / 8) * 64 * (256 / VPFX_RM_WG)), block(VPFX_RM_WG);
+    const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
     hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
                        c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out);
 }

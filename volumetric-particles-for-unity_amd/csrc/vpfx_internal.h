@@ -159,7 +159,16 @@ void   hl_build_grid(vp_ctx* c);                       // GridConsts + mvPos    
 void   hl_build_psys(vp_ctx* c, const float m[16]);
 void   hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p);
 int    hl_z_boundary(const vp_ctx* c, const vp_camera* cam);             //           VPR.cs:642-648
-inline int rm_num_super_tiles(int W, int H) { return ((((W + 15) / 16) + 3) / 4) * ((((H + 15) / 16) + 1) / 2); }   // 64x32 px
+// ray-march screen decomposition: wave = 8x8 px, tile = 16x16 px (4 waves), super-tile = (16 << LX) x (16 << LY) px
+#ifndef VPFX_RM_LX
+#define VPFX_RM_LX 2
+#endif
+#ifndef VPFX_RM_LY
+#define VPFX_RM_LY 1
+#endif
+inline int rm_super_tiles_x(int W) { return (((W + 15) / 16) + (1 << VPFX_RM_LX) - 1) >> VPFX_RM_LX; }
+inline int rm_super_tiles_y(int H) { return (((H + 15) / 16) + (1 << VPFX_RM_LY) - 1) >> VPFX_RM_LY; }
+inline int rm_num_super_tiles(int W, int H) { return rm_super_tiles_x(W) * rm_super_tiles_y(H); }
 void   hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank);  //           VPR.cs:613-632
 void   hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k);
 
