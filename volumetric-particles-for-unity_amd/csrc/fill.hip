@@ -18,7 +18,8 @@
 //     (s_set_gpr_idx), no LDS, no scratch;
 //   * the displacement cubemap is pre-expanded to bilinear footprints: one 16-byte load per covered voxel
 //     instead of four texel fetches (gfx950 has no image/sampler hardware).
-// Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernel is ALU-limited well before it.
+// Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernel is limited well before it by VALU issue and by the
+// L2 request rate of the per-voxel footprint gather.
 #include <cstdlib>
 #include <type_traits>
 
@@ -274,9 +275,9 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 //   stage 1: coverage test, cube addressing, footprint load ISSUED (one load per slice, every lane; lanes
                 //            without a covered voxel fetch entry 0, an L1 hit)
                 //   stage 2: wait for that load only, bilinear + smoothstep + accumulate
-                // with two register sets (a, b), so the load of slice s+1 is in flight while slice s is shaded.  hipcc
-                // cannot express "wait for the older of two loads" here (it emits vmcnt(0) around exec-masked regions),
-                // so the load and its wait are inline asm: loads return in order, hence vmcnt(1) == "the older one landed".
+                // with PIPE register sets, so that PIPE footprint loads are in flight while the oldest slice is shaded.  hipcc
+                // cannot express "wait for the oldest of N loads" here (it emits vmcnt(0) around exec-masked regions), so the
+                // load and its wait are inline asm: loads return in order, hence vmcnt(N-1) == "the oldest one has landed".
                 auto stage1 = [&](int s, float& tx, float& ty, float& d2, bool& hit, f32x4& q) {
                     const float fs = (float)(c0 + s);
                     const float psx = fmaf(fs, Bx, Ax), psy = fmaf(fs, By, Ay), psz = fmaf(fs, Bz, Az);
