@@ -1,0 +1,86 @@
+/* demo_frame.c -- one frame of the hot path through the C ABI alone (no Python, no torch): what a native host (the Unity
+ * plugin shim, a C/C++ engine) links against.  Builds a small deterministic scene, runs
+ *   vp_create -> vp_set_frame -> vp_bin -> vp_fill -> vp_raymarch -> vp_get_stats
+ * and prints the statistics plus image / light-map checksums (tests/test_c_abi.py compares them with the same scene run
+ * through the ctypes binding).
+ *   cc -std=c99 -Iinclude examples/demo_frame.c -Lvolumetric-particles-for-unity_amd -lvpfx -lm -o demo_frame          */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vpfx.h"
+
+/* Unity 5 ParticleSystem.Particle-like record; the ABI takes explicit offsets, so any layout works */
+typedef struct { float position[3]; float velocity[3]; float size; float rotation; float lifetime; float start_lifetime; } particle;
+
+static unsigned lcg(unsigned* s) { *s = *s * 1664525u + 1013904223u; return *s >> 8; }
+static float frand(unsigned* s) { return (float)lcg(s) / 16777216.0f; }
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ != VP_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, vp_last_error(ctx)); return 2; } } while (0)
+
+int main(int argc, char** argv)
+{
+    const int N = 4, NV = 16, P = argc > 1 ? atoi(argv[1]) : 150, W = 96, H = 64, S = 16;
+    vp_ctx* ctx = NULL;
+    vp_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.num_mv[0] = cfg.num_mv[1] = cfg.num_mv[2] = N; cfg.num_voxels = NV; cfg.num_border = 1; cfg.mv_scale = 3.0f;
+    cfg.width = W; cfg.height = H; cfg.device = -1;
+    int rc = vp_create(&cfg, &ctx);
+    if (rc != VP_OK) { fprintf(stderr, "vp_create -> %d: %s\n", rc, vp_last_error(NULL)); return rc == VP_ERR_NO_DEVICE ? 3 : 2; }
+
+    /* light looking down +Z of the world (identity rotation), grid centred on the origin */
+    float light_to_world[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,-40,1};
+    float grid_center[3] = {0, 0, 0};
+    float identity[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1};
+    CHECK(vp_set_frame(ctx, light_to_world, grid_center));
+
+    unsigned seed = 12345u;
+    particle* parts = (particle*)calloc((size_t)P, sizeof(particle));
+    for (int i = 0; i < P; ++i) {
+        for (int k = 0; k < 3; ++k) parts[i].position[k] = (frand(&seed) - 0.5f) * 0.7f * N * 3.0f;
+        parts[i].size = 3.0f * (0.6f + 0.8f * frand(&seed));
+        parts[i].rotation = 360.0f * frand(&seed);
+        parts[i].start_lifetime = 6.0f; parts[i].lifetime = 6.0f * frand(&seed);
+    }
+    vp_particle_layout lay; memset(&lay, 0, sizeof lay);
+    lay.stride = (int32_t)sizeof(particle);
+    lay.off_position = 0; lay.off_size = 24; lay.off_rotation = 28; lay.off_lifetime = 32; lay.off_start_lifetime = 36;
+    CHECK(vp_bin(ctx, parts, P, &lay, identity));
+
+    float* cube = (float*)malloc(sizeof(float) * 6 * S * S);
+    for (int i = 0; i < 6 * S * S; ++i) cube[i] = 0.1f + 0.85f * frand(&seed);
+    vp_fill_params fp; memset(&fp, 0, sizeof fp);
+    fp.opacity_factor = 0.04f; fp.displacement_scale = 0.7f; fp.ambient[0] = fp.ambient[1] = fp.ambient[2] = 0.2f;
+    fp.init_light_intensity = 1.0f; fp.light_near = 0.3f; fp.light_far = 1000.0f; fp.light_cam_distance = 200.0f;
+    fp.cubemap_size = S; fp.cubemap = cube;
+    CHECK(vp_fill(ctx, &fp));
+
+    /* camera at (0, 0, -D) looking at the origin: view space looks down -Z, so camera_to_world = [x, y, -f | pos] */
+    const float D = 0.8f * N * 3.0f;
+    vp_camera cam; memset(&cam, 0, sizeof cam);
+    float c2w[16] = {1,0,0,0, 0,1,0,0, 0,0,-1,0, 0,0,-D,1};
+    float w2c[16] = {1,0,0,0, 0,1,0,0, 0,0,-1,0, 0,0,-D,1};      /* inverse of [R | t] with R = diag(1,1,-1): [R | -R t] */
+    memcpy(cam.camera_to_world, c2w, sizeof c2w); memcpy(cam.world_to_camera, w2c, sizeof w2c);
+    cam.cam_pos[2] = -D; cam.fov_y = 60.0f * 3.14159265358979f / 180.0f; cam.near_clip = 0.3f; cam.far_clip = 1000.0f;
+    vp_raymarch_params rp; memset(&rp, 0, sizeof rp);
+    rp.steps_per_mv = 64; rp.soft_distance = 20;
+    float* img = (float*)malloc(sizeof(float) * 4 * W * H);
+    CHECK(vp_raymarch(ctx, &cam, &rp, img));
+
+    vp_stats st; CHECK(vp_get_stats(ctx, &st));
+    float* lm = (float*)malloc(sizeof(float) * (size_t)(N * NV) * (N * NV));
+    CHECK(vp_read_lightmap(ctx, lm));
+    double s_rgb = 0, s_a = 0, s_lm = 0;
+    for (int i = 0; i < W * H; ++i) { s_rgb += img[4 * i] + img[4 * i + 1] + img[4 * i + 2]; s_a += img[4 * i + 3]; }
+    for (int i = 0; i < N * NV * N * NV; ++i) s_lm += lm[i];
+    printf("particles %lld occupied_mv %lld pairs %lld voxels %lld samples %lld\n", (long long)st.particles, (long long)st.occupied_mv,
+           (long long)st.pairs, (long long)st.voxels_filled, (long long)st.samples);
+    printf("sum_rgb %.6f sum_alpha %.6f sum_lightmap %.6f\n", s_rgb, s_a, s_lm);
+    float ms_fill = 0, ms_rm = 0;
+    vp_last_kernel_ms(ctx, 1, &ms_fill); vp_last_kernel_ms(ctx, 2, &ms_rm);
+    printf("fill %.3f ms, ray-march %.3f ms\n", ms_fill, ms_rm);
+    vp_destroy(ctx);
+    free(parts); free(cube); free(img); free(lm);
+    return 0;
+}
