@@ -10,7 +10,11 @@
  *   here) nor its HLSL (ShaderLab + D3D11 fixed-function units, no dxc/fxc here) can be built or run in this
  *   container.  This file is therefore a restatement written from the reference's source text; it is pinned
  *   only by (1) an independent float64 numpy twin (oracle/numpy_twin.py), (2) analytic known-answer tests
- *   (tests/test_oracle_kat.py), (3) committed golden fixtures generated from (1)+(this file).
+ *   (tests/test_oracle_kat.py), (3) committed golden fixtures generated from (1)+(this file), and (4) the
+ *   one external anchor there is: eight pixels + whole-frame statistics of config C1 recorded in SURVEY.md
+ *   App. C from the surveyor's own independent float64 probe of the shaders, rendered with the reference's
+ *   displacement cubemap asset -- reproduced by this file to 6e-6 (tests/golden/survey_anchors_C1.npz).
+ *   None of these is an output of the reference itself, hence "unpinned".
  *
  * Reference files restated (paths relative to the reference root):
  *   VPR.cs     = Assets/Main Scene/VolumetricParticleRenderer.cs

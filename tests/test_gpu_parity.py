@@ -3,6 +3,7 @@
 Tolerances: bin lists / counts bit-exact (integer work); bricks bit-identical in `exact` mode and within
 1 fp16 ulp in the default fast-reciprocal mode; light map 1e-5 rel; final RGBA 1e-3 abs (north_star).
 """
+import os
 import numpy as np
 import pytest
 
@@ -85,3 +86,17 @@ def test_raymarch_rgba(name):
     ig2 = g2.raymarch(sc.camera(), sc.raymarch_params())
     assert np.abs(io - ig2).max() <= 1e-3
     assert g2.stats()["samples"] <= sg
+
+
+def test_survey_anchor_pixels_with_the_reference_displacement_cubemap():
+    """HIP path against the surveyor's independent anchors (see the same test in test_oracle_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "survey_anchors_C1.npz"))
+    sc = S.make_scene("C1")
+    sc.cubemap = np.ascontiguousarray(g["cubemap_r"].astype(np.float32) / np.float32(255.0))
+    e = E.Engine(sc.config())
+    e.set_frame(sc.light_to_world, sc.grid_center)
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    e.fill(sc.fill_params())
+    img = e.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(img[g["rows"], g["cols"], 0] - g["r"]).max() <= 5e-5 and np.abs(img[g["rows"], g["cols"], 3] - g["a"]).max() <= 5e-5
+    assert abs(float(img[..., 3].mean()) - 0.802) < 1e-3 and abs(float(img[..., :3].max()) - 0.543) < 1e-3

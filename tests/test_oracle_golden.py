@@ -66,6 +66,22 @@ def test_golden_C1_and_survey_anchors():
     assert 0.5 < lm.mean() < 0.54 and 0.79 < img[..., 3].mean() < 0.81      # survey: 0.52 / 0.802
 
 
+def test_survey_anchor_pixels_with_the_reference_displacement_cubemap():
+    """The one check pinned OUTSIDE this repo's code: eight anchor pixels of C1 from the surveyor's independent float64 probe of
+    the reference's shaders, rendered with the reference's displacement cubemap (R bytes / 255).  Provenance
+    of the fixture: tests/golden/make_survey_anchor_fixture.py.  The anchors are printed to 5 decimals."""
+    g = np.load(os.path.join(G, "survey_anchors_C1.npz"))
+    sc = S.make_scene("C1")
+    sc.cubemap = np.ascontiguousarray(g["cubemap_r"].astype(np.float32) / np.float32(255.0))
+    o, img = run(sc)
+    got_r, got_a = img[g["rows"], g["cols"], 0], img[g["rows"], g["cols"], 3]
+    assert np.abs(got_r - g["r"]).max() <= 1.5e-5 and np.abs(got_a - g["a"]).max() <= 1.5e-5
+    assert np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])   # grey ambient + diffuse
+    # the probe's whole-frame numbers for the same run
+    assert abs(o.stats()["samples"] - 15_785_280) < 100 and abs(float(img[..., 3].mean()) - 0.802) < 1e-3
+    assert abs(float(img[..., :3].max()) - 0.543) < 1e-3 and abs(float((img[..., 3] > 0).mean()) - 0.902) < 2e-3
+
+
 def test_golden_C1_clean_binning():
     g = np.load(os.path.join(G, "C1_clean.npz"))
     sc = S.make_scene("C1", size_range=(1.1, 1.9))
