@@ -193,6 +193,8 @@ def test_config2_full_parity():
     np.testing.assert_array_equal(o.bin_counts(), g.bin_counts())
     np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
     assert g.stats()["samples"] <= o.stats()["samples"]               # saturation early-out skips exact no-ops only
+    st = g.stats()
+    assert st["occupied_mv"] == 1785 and st["pairs"] == 48728 and st["max_pairs_per_mv"] == 70
 
 
 def test_config3_full_parity_and_properties():
