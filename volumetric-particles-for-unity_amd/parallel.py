@@ -92,6 +92,7 @@ class SlabPipeline:
         self._second = None
         self._final = None
         self._pad = {}
+        self._tiles_ok = False
         self._stage = None         # gloo + device tensors: stage the image exchange through host memory
         self._into_tensor = True   # all_gather_into_tensor (one contiguous receive buffer, no per-rank copies) if supported
 
@@ -190,6 +191,19 @@ class SlabPipeline:
                 dist.broadcast(second, src=straddler, group=self.group)
             images = [second if (r == straddler and which == "under") else prim[r] for r, which, kind in plan]
             return self.eng.blend(images, [kind for _, _, kind in plan])
+        try:
+            return self._render_tiles(primary, under, plan, straddler, result)
+        except (RuntimeError, NotImplementedError) as e:
+            if self._tiles_ok:                     # it worked before: a real failure, not a missing collective
+                raise
+            # a backend without all_to_all / scatter / gather: every rank sees the same error on the first frame and
+            # switches to the one-collective form for good
+            import warnings
+            warnings.warn(f"tiles exchange unavailable ({e}); falling back to exchange='all_gather'")
+            self.exchange = "all_gather"
+            return self.render(cam, rp, result)
+
+    def _render_tiles(self, primary, under, plan, straddler, result):
         send, npix, piece = self._pieces(primary, "primary")
         if self._img_all is None:
             self._img_all = torch.empty_like(send)                     # [world, piece, 4]: piece `rank` of every rank's primary image
@@ -207,6 +221,7 @@ class SlabPipeline:
             kinds.append(kind)
         mine = self.eng.blend(images, kinds)                           # [piece, 4]
         self._gather_to(self._final, mine, 0, result == "all")
+        self._tiles_ok = True
         if result != "all" and self.rank != 0:
             return None
         return self._final.view(-1, 4)[:npix].view(primary.shape)
