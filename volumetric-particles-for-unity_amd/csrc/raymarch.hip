@@ -11,8 +11,9 @@
 // for both phases -- and inside a slab visits the (x,y) cells its ray crosses in the reference's sorted order
 // (rank table built on the host from the same keys as SortMetavoxelSlicesFarToNearFromEye).  Per MV it runs the
 // reference's back-to-front sample loop with software trilinear filtering of the RGBA16F brick (no image
-// hardware on gfx950) and applies the reference's blend equation in registers.  Rays stop once the UNDER phase
-// has saturated (1 - dst.a == 0: every later blend is an exact no-op).
+// hardware on gfx950) and blends in registers, front to back (the reverse of the reference's OVER phase, then its UNDER
+// phase -- the same image up to rounding; the FLAGS kernel keeps the literal sequence).  Rays stop once saturated
+// (1 - dst.a == 0: every later blend is a no-op).
 // Bound: compulsory HBM traffic is one read of every contributing brick + one image store; the sampling itself
 // is L1/L2-resident (64 B requested per sample).
 #include "vpfx_internal.h"
@@ -318,9 +319,11 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #ifndef VPFX_RM_WAVES
 #define VPFX_RM_WAVES 5
 #endif
-#define VPFX_RM_LB __launch_bounds__(64, VPFX_RM_WAVES)
+#ifndef VPFX_RM_WAVES_PARTIAL
+#define VPFX_RM_WAVES_PARTIAL VPFX_RM_WAVES
+#endif
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
-__global__ void VPFX_RM_LB
+__global__ void __launch_bounds__(64, (PARTIAL || FLAGS) ? VPFX_RM_WAVES_PARTIAL : VPFX_RM_WAVES)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
@@ -399,7 +402,16 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     const int nxy = k.Nx * k.Ny;
     bool done = !(tg0 <= tg1);
 
-    for (int zz = k.z0; zz < k.z1 && !done; ++zz) {
+    // Slab order.  The reference draws phase A (zz <= zBoundary) zz ascending, cells far -> near, blended OVER, then phase B
+    // (zz > zBoundary) zz ascending, cells near -> far, blended UNDER (VPR.cs:652-711): front to back that is the REVERSE of
+    // phase A followed by phase B.  Premultiplied over/under are the same associative operator seen from the two ends, so the
+    // default kernel composites everything front to back with UNDER -- equal up to rounding (~1e-7) -- which lets a ray stop
+    // as soon as it is saturated in EITHER phase (a top-down camera is all phase A).  The FLAGS kernel keeps the reference's
+    // literal sequence: the UNORM8 render-target emulation re-quantises after every blend, so there the order is the result.
+    const int nslab = k.z1 - k.z0;
+    const int nA = min(max(k.zB - k.z0 + 1, 0), nslab);                                    // owned phase-A slabs
+    for (int it = 0; it < nslab && !done; ++it) {
+        const int zz = (!FLAGS && it < nA) ? k.z0 + nA - 1 - it : k.z0 + it;
         // parameter range of the ray inside slab zz
         float ta, tb;
         if (R.dgz != 0.f) {
@@ -410,11 +422,13 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             ta = tg0; tb = tg1;
         }
         if (!(ta <= tb)) continue;
-        const bool over = zz <= k.zB;                                                      // VPR.cs:667 vs :697
+        const bool phaseA = zz <= k.zB;                                                    // VPR.cs:667 vs :697
+        const bool over = FLAGS && phaseA;                                                 // literal OVER, cells far -> near
+        F4& d = (PARTIAL && !phaseA) ? dstB : dstA;
         const int* occ = brick_index + zz * nxy;
         int last = over ? 0x7fffffff : -1;
         for (;;) {
-            // select the next occupied cell of this slab in draw order (rank descending for OVER, ascending for UNDER)
+            // select the next occupied cell of this slab: rank ascending = near -> far (descending for the literal OVER order)
             int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
             float t = ta;
             for (int guard = 0; guard < 2 * (k.Nx + k.Ny) + 8; ++guard) {
@@ -442,24 +456,21 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             if (!march_mv<NV, WRAP, FLAGS>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
-                src = over ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
+                src = phaseA ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
             if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
                 const float ia = 1.0f - src.w;
-                dstA.x = src.x + dstA.x * ia; dstA.y = src.y + dstA.y * ia; dstA.z = src.z + dstA.z * ia; dstA.w = src.w + dstA.w * ia;
+                d.x = src.x + d.x * ia; d.y = src.y + d.y * ia; d.z = src.z + d.z * ia; d.w = src.w + d.w * ia;
             } else {                            // Blend OneMinusDstAlpha One                                  VPR.cs:688-691
-                F4& d = PARTIAL ? dstB : dstA;
                 const float ia = 1.0f - d.w;
                 d.x = src.x * ia + d.x; d.y = src.y * ia + d.y; d.z = src.z * ia + d.z; d.w = src.w * ia + d.w;
             }
             if (FLAGS && (k.flags & VP_RM_QUANTIZE_UNORM8)) {   // particlesRT is ARGB32: the ROP stores UNORM8 (Q19)    VPR.cs:228
-                F4& d = (PARTIAL && !over) ? dstB : dstA;
                 d.x = unorm8(d.x); d.y = unorm8(d.y); d.z = unorm8(d.z); d.w = unorm8(d.w);
             }
         }
-        if (!over && early_out) {
-            const F4& d = PARTIAL ? dstB : dstA;
-            if (1.0f - d.w <= k.alpha_cutoff) done = true;      // every later UNDER blend multiplies by (1 - dst.a) == 0
-        }
+        // saturated: everything farther along the ray is multiplied by (1 - dst.a) == 0.  (A saturated phase-A image of a slab
+        // also hides the slab's own phase-B image, which is composited behind it.)
+        if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
     }
 
     const size_t pi = (size_t)row * k.W + col;
