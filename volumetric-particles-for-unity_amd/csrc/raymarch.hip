@@ -427,26 +427,56 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         F4& d = (PARTIAL && !phaseA) ? dstB : dstA;
         const int* occ = brick_index + zz * nxy;
         int last = over ? 0x7fffffff : -1;
-        for (;;) {
-            // select the next occupied cell of this slab: rank ascending = near -> far (descending for the literal OVER order)
-            int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
+        // (x,y) cell of this slab that contains the ray at parameter t (-1 outside the grid); advances t to that cell's exit
+        auto cell_at = [&](float& t) -> int {
+            const float tm = t + eps;
+            const float px = fmaf(tm, R.dgx, R.ogx), py = fmaf(tm, R.dgy, R.ogy);
+            const int cx = (int)floorf(px), cy = (int)floorf(py);
+            const float tx = R.dgx > 0.f ? R.ivx * ((float)(cx + 1) - R.ogx) : (R.dgx < 0.f ? R.ivx * ((float)cx - R.ogx) : 3.0e38f);
+            const float ty = R.dgy > 0.f ? R.ivy * ((float)(cy + 1) - R.ogy) : (R.dgy < 0.f ? R.ivy * ((float)cy - R.ogy) : 3.0e38f);
+            t = fmaxf(fminf(tx, ty), t + eps);
+            return (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) ? cy * k.Nx + cx : -1;
+        };
+        const int max_cells = 2 * (k.Nx + k.Ny) + 8;
+        // The reference's order inside a slab is the GLOBAL (x,y) sort (rank), not the order along this ray.  Almost always
+        // the two agree (ranks ascend along the ray): one look-ahead walk checks that, and the cells are then marched as a
+        // second walk meets them -- O(cells) instead of one selection walk per cell (O(cells^2): a ray running along a slab
+        // crosses up to Nx + Ny cells).  Otherwise, and for the literal OVER order, fall back to selection by rank.
+        bool stream = !over;
+        if (stream) {
             float t = ta;
-            for (int guard = 0; guard < 2 * (k.Nx + k.Ny) + 8; ++guard) {
-                const float tm = t + eps;
-                const float px = fmaf(tm, R.dgx, R.ogx), py = fmaf(tm, R.dgy, R.ogy);
-                const int cx = (int)floorf(px), cy = (int)floorf(py);
-                const float tx = R.dgx > 0.f ? R.ivx * ((float)(cx + 1) - R.ogx) : (R.dgx < 0.f ? R.ivx * ((float)cx - R.ogx) : 3.0e38f);
-                const float ty = R.dgy > 0.f ? R.ivy * ((float)(cy + 1) - R.ogy) : (R.dgy < 0.f ? R.ivy * ((float)cy - R.ogy) : 3.0e38f);
-                if (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) {
-                    const int cell = cy * k.Nx + cx;
-                    if (occ[cell] >= 0) {
+            int prev = -1;
+            for (int guard = 0; guard < max_cells; ++guard) {
+                const int cell = cell_at(t);
+                if (cell >= 0 && occ[cell] >= 0) { const int r = rank[cell]; if (r < prev) stream = false; prev = r; }
+                if (!(t < tb)) break;
+            }
+        }
+        float tw = ta;                                          // streaming walk position
+        int walked = 0;
+        bool walk_done = false;
+        for (;;) {
+            int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
+            if (stream) {
+                // next occupied cell along the ray (a cell met twice in a row -- the eps nudges -- is taken once)
+                while (!walk_done && walked < max_cells) {
+                    const int cell = cell_at(tw);
+                    ++walked;
+                    if (!(tw < tb)) walk_done = true;
+                    if (cell >= 0 && occ[cell] >= 0) { const int r = rank[cell]; if (r > last) { best_r = r; best_cell = cell; break; } }
+                }
+            } else {
+                // select the next occupied cell of this slab: rank ascending = near -> far (descending for the literal OVER order)
+                float t = ta;
+                for (int guard = 0; guard < max_cells; ++guard) {
+                    const int cell = cell_at(t);
+                    if (cell >= 0 && occ[cell] >= 0) {
                         const int r = rank[cell];
                         const bool better = over ? (r < last && r > best_r) : (r > last && r < best_r);
                         if (better) { best_r = r; best_cell = cell; }
                     }
+                    if (!(t < tb)) break;
                 }
-                t = fmaxf(fminf(tx, ty), t + eps);
-                if (!(t < tb)) break;
             }
             if (best_cell < 0) break;
             last = best_r;
