@@ -9,7 +9,7 @@
 //     full 128-byte lines of the brick), persistent along the light axis: it walks its MV column zz = z0..z1
 //     carrying the transmitted light in a register, so the z-order dependency never leaves the chip and the
 //     light map is written once;
-//   * workgroups are dispatched heaviest-column-first (k_col_order) to bound the tail;
+//   * workgroups are dispatched heaviest-column-first (k_col_weight + k_col_rank) to bound the tail;
 //   * per (wave, particle): the column is a line ps(s) = A + s*B in particle space, so coverage is a quadratic
 //     in the slice index; each lane solves it, a DPP OR-reduction merges the per-lane slice masks, and only the
 //     wave-uniform slice range is tested (exact test unchanged: |ps|^2 <= 0.25, Fill.shader:172);
