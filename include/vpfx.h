@@ -163,7 +163,8 @@ int  vp_unpin_host_buffer(vp_ctx* ctx, void* ptr);
 int  vp_set_frame(vp_ctx* ctx, const float light_to_world[16], const float grid_center[3]);
 
 /* BinParticlesToMetavoxels (VPR.cs:397-457) = vp_upload_particles + vp_bin_resident.
- * `particles` is host memory (e.g. a pinned ParticleSystem.Particle[]). */
+ * `particles` is host memory (e.g. a pinned ParticleSystem.Particle[]).  A particle whose position or size is not finite
+ * is skipped (the reference indexes its grid with (int)NaN there, VPR.cs:434-438). */
 int  vp_bin(vp_ctx* ctx, const void* particles, int32_t count, const vp_particle_layout* layout,
             const float psys_local_to_world[16]);
 int  vp_upload_particles(vp_ctx* ctx, const void* particles, int32_t count,

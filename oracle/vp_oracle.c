@@ -347,6 +347,12 @@ typedef struct { int lo[3], hi[3]; } cand_range;
 /* candidate MV range of one particle                                                 VPR.cs:418-432 */
 static cand_range particle_candidates(const vpo_ctx* c, v3 ws, float size)
 {
+    /* A particle with a non-finite position or size is skipped.  The reference's behaviour for it is undefined (C# (int)NaN in
+     * :434-438 indexes the MV grid with int.MinValue); skipping is the defined behaviour of this implementation (vpfx.h). */
+    if (!(isfinite(ws.x) && isfinite(ws.y) && isfinite(ws.z) && isfinite(size))) {
+        cand_range none = { {0, 0, 0}, {-1, -1, -1} };
+        return none;
+    }
     v3 ls = mul_point(c->Linv, ws);                                  /* lsParticlePos  :419 */
     v3 pio = v3_make((ls.x - c->lsO.x) / c->s, (ls.y - c->lsO.y) / c->s, (ls.z - c->lsO.z) / c->s);  /* :422 */
     v3 pi = v3_make(pio.x + (float)c->Nx * 0.5f, pio.y + (float)c->Ny * 0.5f, pio.z + (float)c->Nz * 0.5f); /* :423 */

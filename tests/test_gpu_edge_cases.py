@@ -46,6 +46,33 @@ def test_empty_particle_array():
     np.testing.assert_array_equal(ig, 0.0)
 
 
+def test_non_finite_particles_are_skipped():
+    """NaN / inf positions or sizes (undefined in the reference: (int)NaN indexes its grid) are skipped; everything else is
+    unchanged, ids included.  Zero-size particles cover nothing."""
+    sc = S.make_scene("T0")
+    ref_o, ref_g = both(sc)
+    img_ref = ref_g.raymarch(sc.camera(), sc.raymarch_params())
+    P = len(sc.particles)
+    extra = np.repeat(sc.particles[:6], 1, axis=0).copy()
+    raw = extra.view(np.float32).reshape(6, -1)
+    lay = sc.layout
+    pos, size = lay.off_position // 4, lay.off_size // 4
+    raw[0, pos] = np.nan
+    raw[1, pos + 1] = np.inf
+    raw[2, pos + 2] = -np.inf
+    raw[3, size] = np.nan
+    raw[4, size] = np.inf
+    raw[5, size] = 0.0
+    sc.particles = np.concatenate([sc.particles, extra])
+    o, g = both(sc)
+    assert g.stats()["particles"] == P + 6
+    np.testing.assert_array_equal(g.bin_counts(), ref_g.bin_counts())
+    np.testing.assert_array_equal(o.bin_counts(), ref_o.bin_counts())
+    img = g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.isfinite(img).all() and np.array_equal(img, img_ref)
+    assert np.array_equal(g.read_lightmap(), ref_g.read_lightmap())
+
+
 def test_fade_and_radians_and_moved_particle_system():
     sc = S.make_scene("x", dims=(6, 16, 300, 96, 64), rotation_in_radians=True, fade=1)
     rot = S.quat_to_matrix((0.1, 0.3, -0.2, 0.927))

@@ -105,6 +105,8 @@ k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restri
         r[14] = fmaf(r[6], dz, fmaf(r[5], dy, r[4] * dx));
         r[15] = fmaf(r[10], dz, fmaf(r[9], dy, r[8] * dx));
     }
+    // a particle with a non-finite position or size is skipped (undefined in the reference: C# (int)NaN, :434-438)
+    if (!(fabsf(w.x) < INFINITY && fabsf(w.y) < INFINITY && fabsf(w.z) < INFINITY && fabsf(w.w) < INFINITY)) return;
     // lsParticlePos = light.worldToLocal * ws                                                  :419
     const float lx = ((g.Linv[0] * w.x + g.Linv[1] * w.y) + g.Linv[2] * w.z) + g.Linv[3];
     const float ly = ((g.Linv[4] * w.x + g.Linv[5] * w.y) + g.Linv[6] * w.z) + g.Linv[7];
