@@ -111,6 +111,15 @@ def test_many_particles_in_one_metavoxel():
     assert g.stats()["max_pairs_per_mv"] > 256
 
 
+def test_more_particles_in_one_metavoxel_than_the_lds_sort_holds():
+    """> 4096 particles in one MV: the list still comes out in ascending particle index (the reference's summation order), so
+    the bricks stay bit-identical to the oracle."""
+    sc = S.make_scene("pile", dims=(1, 16, 6000, 48, 32))
+    sc.particles["position"] *= 0.02
+    o, g, _, _ = check(sc)
+    assert g.stats()["max_pairs_per_mv"] > 4096
+
+
 def test_light_depth_map_and_scene_depth():
     sc = S.make_scene("T0")
     nv, N = sc.nv, sc.N[0]

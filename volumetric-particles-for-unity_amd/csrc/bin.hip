@@ -231,9 +231,14 @@ k_sort_lists(const int* __restrict__ occ_list, const int* __restrict__ offsets, 
     __shared__ int s_ids[SORT_CAP];
     const int mi = occ_list[blockIdx.x];
     const int off = offsets[mi], n = offsets[mi + 1] - off;
-    if (n > SORT_CAP) {      // pathological list: keep arrival order (only the fp32 density sum order changes)
-        for (int i = threadIdx.x; i < n; i += 256) out[off + i] = in[off + i];
-        if (threadIdx.x == 0) atomicAdd(&meta->unsorted_lists, 1);
+    if (n > SORT_CAP) {      // pathological list (> 4096 particles in one MV): the same rank sort straight from global memory
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int v = in[off + i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += (in[off + j] < v) ? 1 : 0;
+            out[off + rank] = v;
+        }
+        if (threadIdx.x == 0) atomicAdd(&meta->unsorted_lists, 1);      // counts the lists that took this slow path
         return;
     }
     for (int i = threadIdx.x; i < n; i += 256) s_ids[i] = in[off + i];
