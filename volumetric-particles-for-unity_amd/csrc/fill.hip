@@ -26,7 +26,7 @@
 #include "vpfx_internal.h"
 
 #ifndef VPFX_FILL_PIPE
-#define VPFX_FILL_PIPE 4      // at most 4 (deeper groups were measured: no further gain)
+#define VPFX_FILL_PIPE 4      // 2..6; measured at C3: 2 -> 5.33 ms, 3 -> 5.07 (4 waves/SIMD), 4 -> 4.80 (3 waves/SIMD)
 #endif
 
 namespace {
@@ -158,8 +158,11 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
 
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
 // (propagation with T_in = 1) to light_out.
+#ifndef VPFX_FILL_WAVES
+#define VPFX_FILL_WAVES 1
+#endif
 template <int NV, bool EXACT, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, VPFX_FILL_WAVES)
 k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
@@ -319,13 +322,16 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                     }
                     s_next = s + 2 * D;
                 };
-                // full groups of 2*PIPE slices, then (at most) one group of each smaller depth: with PIPE = 4 the remainder is
-                // < 8 slices, so {6, 4, 2} + 1 covers it
-                static_assert(PIPE == 4, "the remainder schedule below is written for PIPE = 4");
+                // full groups of 2*PIPE slices, then (at most) one group of each smaller depth: the remainder is < 2*PIPE
+                // slices, so depths PIPE-1 .. 1 and one single slice cover it.  (Sequential ifs on purpose: an else-if chain
+                // or a loop over the depth made hipcc keep every depth's register sets alive at once.)
+                static_assert(PIPE >= 2 && PIPE <= 6, "remainder schedule written for PIPE = 2..6");
 #pragma unroll 1
-                while (s_next + 7 <= s_last) group(std::integral_constant<int, 4>{});
-                if (s_next + 5 <= s_last) group(std::integral_constant<int, 3>{});
-                if (s_next + 3 <= s_last) group(std::integral_constant<int, 2>{});
+                while (s_next + 2 * PIPE - 1 <= s_last) group(std::integral_constant<int, PIPE>{});
+                if constexpr (PIPE >= 6) { if (s_next + 9 <= s_last) group(std::integral_constant<int, 5>{}); }
+                if constexpr (PIPE >= 5) { if (s_next + 7 <= s_last) group(std::integral_constant<int, 4>{}); }
+                if constexpr (PIPE >= 4) { if (s_next + 5 <= s_last) group(std::integral_constant<int, 3>{}); }
+                if constexpr (PIPE >= 3) { if (s_next + 3 <= s_last) group(std::integral_constant<int, 2>{}); }
                 if (s_next + 1 <= s_last) group(std::integral_constant<int, 1>{});
                 if (s_next <= s_last) {
                     const int s = s_next;
