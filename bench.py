@@ -183,6 +183,11 @@ def main():
             r["traffic"] = t["traffic_bytes"] if t else None
             if t:
                 r["traffic_source"] = f"profiles/traffic_{args.config}.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        # what actually limits the two kernels (rocprofv3 PMC passes of this command, profiles/ + DESIGN.md 3.4): not HBM
+        roofs["fill"]["limiter"] = ("VALU issue (~80 % busy) + L2 request rate / L1 tag rate of the per-voxel cube-map gather "
+                                    "(~1.0 G TCP_TCC_READ_REQ, ~2.0 G TCP accesses per launch); HBM is at ~0.75 TB/s")
+        roofs["raymarch"]["limiter"] = ("VALU issue (~72 % busy) + L1/TA rate of the trilinear footprint loads "
+                                        "(4 x 16 B per sample per lane, 64 B/clk/CU); HBM is at ~1.9 TB/s")
         dom = "fill" if fill_ms >= rm_ms else "raymarch"
         executed = (voxels, samples)
         if ref_units is not None:
