@@ -377,8 +377,10 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
     const int tile = blockIdx.x % TPM;
     const int xx = col % g.Nx, yy = col / g.Nx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = (tile % TW) * 16 + (wave & 1) * 8 + (lane & 7);      // wave = 8x8 columns: most compact footprint,
-    const int py = (tile / TW) * 16 + (wave >> 1) * 8 + (lane >> 3);    // highest lane utilisation in covered slices
+    // a streaming pass: wave = 16 columns x 4 rows, so that every row a wave touches is one full 128-byte line of the
+    // scratch (float2) and of the brick (4 x f16)
+    const int px = (tile % TW) * 16 + (lane & 15);
+    const int py = (tile / TW) * 16 + wave * 4 + (lane >> 4);
     const int LW = g.Nx * NV;
     const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
     const float fnv = (float)NV;
