@@ -151,9 +151,12 @@ def main():
     st = eng.stats()
     counts = torch.tensor([st["voxels_filled"], st["samples"], st["occupied_mv"], st["pairs"], st["bricks_sampled"]],
                           dtype=torch.float64, device=device)
+    stage_max = torch.tensor([float(np.mean(k_bin)), float(np.mean(k_fill)), float(np.mean(k_rm)), float(np.mean(k_fin)) if k_fin else 0.0],
+                             dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(stage_max, op=dist.ReduceOp.MAX)          # slowest rank per stage (kernel time, HIP events)
     dt = float(t.item())
     voxels, samples, occupied, pairs, bricks_sampled = [float(x) for x in counts.tolist()]
 
@@ -188,6 +191,10 @@ def main():
                                     "(~1.0 G TCP_TCC_READ_REQ, ~2.0 G TCP accesses per launch); HBM is at ~0.75 TB/s")
         roofs["raymarch"]["limiter"] = ("VALU issue (~72 % busy) + L1/TA rate of the trilinear footprint loads "
                                         "(4 x 16 B per sample per lane, 64 B/clk/CU); HBM is at ~1.9 TB/s")
+        smax = [float(x) for x in stage_max.tolist()]
+        # whole-job algorithmic bytes (all ranks): bricks + light map + pair records; bricks sampled + the image
+        fill_bytes_job = occupied * (8 * nv ** 3 + 8 * nv ** 2) + 84 * pairs
+        rm_bytes_job = bricks_sampled * 8 * nv ** 3 + 16 * sc.width * sc.height
         dom = "fill" if fill_ms >= rm_ms else "raymarch"
         executed = (voxels, samples)
         if ref_units is not None:
@@ -209,10 +216,18 @@ def main():
                        "work_unit": "voxels + executed samples of the 1-GPU job (fixed for every N)",
                        "samples_executed_all_ranks": int(executed[1]),
                        "max_abs_rgba_diff_vs_1gpu_frame": shard_err},
-            "fill_mvoxels_per_s": voxels / (fill_ms * 1e-3) / 1e6 if world == 1 else None,
-            "raymarch_msamples_per_s": samples / (rm_ms * 1e-3) / 1e6 if world == 1 else None,
+            # absolute rates: per stage against that stage's kernel time on the slowest rank (fill = local + finish for N > 1),
+            # and for the whole frame (everything incl. the exchanges)
+            "fill_mvoxels_per_s": voxels / ((smax[1] + smax[3]) * 1e-3) / 1e6,
+            "raymarch_msamples_per_s": samples / (smax[2] * 1e-3) / 1e6,
+            "frame_mvoxels_per_s": voxels / (dt / args.steps) / 1e6,
+            "frame_msamples_per_s": samples / (dt / args.steps) / 1e6,
+            "fill_frac_of_hbm_roofline": (fill_bytes_job / ((smax[1] + smax[3]) * 1e-3) / 1e9) / (HBM_PEAK_GBS * world),
+            "raymarch_frac_of_hbm_roofline": (rm_bytes_job / (smax[2] * 1e-3) / 1e9) / (HBM_PEAK_GBS * world),
             "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms,
                          "fill_finish_kernel": float(np.mean(k_fin)) if k_fin else None},
+            "stage_ms_slowest_rank": {"bin": smax[0], "fill_kernel": smax[1], "raymarch_kernel": smax[2],
+                                      "fill_finish_kernel": smax[3] if world > 1 else None},
             "roofline": dict(roofs[dom], stage=dom),
             "roofline_all": roofs,
         }
