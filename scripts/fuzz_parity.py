@@ -1,0 +1,101 @@
+"""Randomised HIP-vs-oracle parity sweep (GPU box): random grids (cubic and not), voxel counts, borders, metavoxel scales, particle
+sets, light rotations, particle-system transforms, cameras all around (inside too), fade / radians / soft-distance / step options,
+random light depth maps and scene depth.  Every case checks: identical bin counts, bricks (bit-identical in exact mode, <= 1 fp16
+ulp in fast mode), light map, RGBA <= 1e-3 and -- with the early-out off -- the oracle's sample count.
+usage: fuzz_parity.py [cases] [first_seed]"""
+import math
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+from __graft_entry__ import load_package; load_package()
+from vpfx_amd import scene as S, engine as E
+from oracle import oracle as O
+
+
+def rand_quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return tuple(q)            # (x, y, z, w)
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    nv = int(rng.choice([16, 16, 32]))
+    N = int(rng.integers(1, 7 if nv == 16 else 5))
+    P = int(rng.integers(0, 500))
+    W, H = int(rng.integers(17, 140)), int(rng.integers(9, 100))
+    border = int(rng.choice([0, 1, 1, 2]))
+    lo = rng.uniform(0.3, 1.2)
+    sc = S.make_scene("fuzz", seed=seed, dims=(N, nv, P, W, H), border=border, fade=int(rng.integers(0, 2)),
+                      size_range=(lo, lo + rng.uniform(0.1, 1.2)), rotation_in_radians=bool(rng.integers(0, 2)))
+    if rng.random() < 0.5:      # non-cubic grid
+        sc.N = (int(rng.integers(1, N + 2)), int(rng.integers(1, N + 2)), int(rng.integers(1, N + 2)))
+    sc.mv_scale = float(rng.choice([3.0, 3.0, rng.uniform(1.0, 4.0)]))
+    if rng.random() < 0.6:
+        sc.light_to_world = S.to_colmajor16(S.trs(tuple(rng.uniform(-30, 30, 3)), S.quat_to_matrix(rand_quat(rng))))
+    if rng.random() < 0.5:
+        sc.grid_center = rng.uniform(-2, 2, 3).astype(np.float32)
+    if rng.random() < 0.5:
+        sc.psys_local_to_world = S.to_colmajor16(S.trs(tuple(rng.uniform(-1.5, 1.5, 3)), S.quat_to_matrix(rand_quat(rng))))
+    sc.steps = int(rng.choice([16, 64, 64, 100]))
+    sc.soft_distance = int(rng.choice([1, 5, 20, 50]))
+    D = 0.8 * max(sc.N) * sc.mv_scale
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d)
+    pos = d * D * rng.uniform(0.05, 1.4) + np.asarray(sc.grid_center, dtype=np.float64)
+    sc.set_camera(tuple(pos), target=tuple(np.asarray(sc.grid_center, dtype=np.float64) + rng.uniform(-1, 1, 3)))
+    if rng.random() < 0.3:
+        lm = np.ones((sc.N[1] * nv, sc.N[0] * nv), dtype=np.float32)
+        y0, x0 = rng.integers(0, lm.shape[0]), rng.integers(0, lm.shape[1])
+        lm[y0:y0 + lm.shape[0] // 2, x0:x0 + lm.shape[1] // 2] = np.float32(rng.uniform(0.19, 0.21))
+        sc.light_depth_map = lm
+    if rng.random() < 0.3:
+        sd = np.full((H, W), 1.0e30, dtype=np.float32)
+        sd[: H // 2] = np.float32(D * rng.uniform(0.3, 1.2))
+        sc.scene_depth = sd
+    exact = bool(rng.integers(0, 2))
+    o = O.Oracle(sc.config())
+    g = E.Engine(sc.config(), exact=exact, early_out=False)
+    ge = E.Engine(sc.config(), exact=exact)
+    for x in (o, g, ge):
+        x.set_frame(sc.light_to_world, sc.grid_center)
+        x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        x.fill(sc.fill_params())
+    co = o.bin_counts()
+    assert np.array_equal(co, g.bin_counts()), "bin counts"
+    worst = 0
+    for zz, yy, xx in zip(*np.nonzero(co)):
+        a, b = o.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32), g.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32)
+        worst = max(worst, int(np.abs(a - b).max()))
+    assert worst <= (0 if exact else 1), f"brick ulp {worst} (exact={exact})"
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    cam, rp = sc.camera(), sc.raymarch_params()
+    io, ig, ie = o.raymarch(cam, rp), g.raymarch(cam, rp), ge.raymarch(cam, rp)
+    err, err_e = float(np.abs(io - ig).max()), float(np.abs(io - ie).max())
+    assert err <= 1e-3 and err_e <= 1e-3, f"rgba {err} / early-out {err_e}"
+    so, sg = o.stats()["samples"], g.stats()["samples"]
+    assert so == sg, f"samples {so} vs {sg}"                       # every lattice sample of the oracle, none more
+    assert ge.stats()["samples"] <= sg
+    for x in (g, ge):
+        x.close()
+    return dict(N=sc.N, nv=nv, P=P, border=border, occupied=int(o.stats()["occupied_mv"]), samples=int(so), zb=int(o.z_boundary(cam)),
+                exact=exact, rgba_err=err, brick_ulp=worst)
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0, bad, worst = time.time(), 0, 0.0
+    for seed in range(first, first + cases):
+        try:
+            r = one_case(seed)
+            worst = max(worst, r["rgba_err"])
+            print(f"seed {seed}: ok  {r}", flush=True)
+        except (AssertionError, Exception) as e:
+            bad += 1
+            print(f"seed {seed}: FAIL {e}", flush=True)
+    print(f"{cases} cases, {bad} failures, worst rgba err {worst:.2e}, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)

@@ -398,7 +398,6 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         tg1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
         tg0 = fmaxf(tg0, ((float)R.tCameraG - 2.0f) * k.mvStep);                           // nothing is sampled behind the camera
     }
-    const float eps = 1.0e-4f;
     const int nxy = k.Nx * k.Ny;
     bool done = !(tg0 <= tg1);
 
@@ -427,15 +426,25 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         F4& d = (PARTIAL && !phaseA) ? dstB : dstA;
         const int* occ = brick_index + zz * nxy;
         int last = over ? 0x7fffffff : -1;
-        // (x,y) cell of this slab that contains the ray at parameter t (-1 outside the grid); advances t to that cell's exit
-        auto cell_at = [&](float& t) -> int {
-            const float tm = t + eps;
-            const float px = fmaf(tm, R.dgx, R.ogx), py = fmaf(tm, R.dgy, R.ogy);
-            const int cx = (int)floorf(px), cy = (int)floorf(py);
-            const float tx = R.dgx > 0.f ? R.ivx * ((float)(cx + 1) - R.ogx) : (R.dgx < 0.f ? R.ivx * ((float)cx - R.ogx) : 3.0e38f);
-            const float ty = R.dgy > 0.f ? R.ivy * ((float)(cy + 1) - R.ogy) : (R.dgy < 0.f ? R.ivy * ((float)cy - R.ogy) : 3.0e38f);
-            t = fmaxf(fminf(tx, ty), t + eps);
-            return (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) ? cy * k.Nx + cx : -1;
+        // Walk of the (x,y) cells the ray crosses inside this slab, t in [ta, tb]: an integer DDA -- the cell index is stepped
+        // across whichever cell face the ray reaches first and never re-derived from a position, so no cell the line crosses is
+        // skipped, however short the crossing (a walk that re-locates itself at "t + epsilon" skips crossings shorter than its
+        // epsilon, and with them the occasional lattice sample: measured 1 sample in 2e5).  Which metavoxel a sample belongs to
+        // is decided by the reference's own box test inside march_mv; the walk only has to offer every candidate.
+        // The only state of a walk is the integer cell (cx, cy): everything else is recomputed from it, so that little stays
+        // live across the march of a metavoxel.
+        auto walk_start = [&](int& cx, int& cy) { cx = (int)floorf(fmaf(ta, R.dgx, R.ogx)); cy = (int)floorf(fmaf(ta, R.dgy, R.ogy)); };
+        // returns the current cell (-1: outside the grid) and steps to the next one (branch-free); fin is set with the last cell
+        auto walk_step = [&](int& cx, int& cy, bool& fin) -> int {
+            // parameter at which the ray leaves cell column cx / cell row cy (from the integer index, never accumulated)
+            const float tx = R.dgx != 0.f ? R.ivx * ((float)cx + ((R.dgx > 0.f ? 1.0f : 0.0f) - R.ogx)) : 3.0e38f;
+            const float ty = R.dgy != 0.f ? R.ivy * ((float)cy + ((R.dgy > 0.f ? 1.0f : 0.0f) - R.ogy)) : 3.0e38f;
+            const int cur = (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) ? cy * k.Nx + cx : -1;
+            fin = !(fminf(tx, ty) < tb);
+            const bool stepx = tx < ty;
+            cx += stepx ? (R.dgx > 0.f ? 1 : -1) : 0;
+            cy += stepx ? 0 : (R.dgy > 0.f ? 1 : -1);
+            return cur;
         };
         const int max_cells = 2 * (k.Nx + k.Ny) + 8;
         // The reference's order inside a slab is the GLOBAL (x,y) sort (rank), not the order along this ray.  Almost always
@@ -444,38 +453,38 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         // crosses up to Nx + Ny cells).  Otherwise, and for the literal OVER order, fall back to selection by rank.
         bool stream = !over;
         if (stream) {
-            float t = ta;
-            int prev = -1;
-            for (int guard = 0; guard < max_cells; ++guard) {
-                const int cell = cell_at(t);
+            int cx, cy, prev = -1;
+            walk_start(cx, cy);
+            bool fin = false;
+            for (int guard = 0; guard < max_cells && !fin; ++guard) {
+                const int cell = walk_step(cx, cy, fin);
                 if (cell >= 0 && occ[cell] >= 0) { const int r = rank[cell]; if (r < prev) stream = false; prev = r; }
-                if (!(t < tb)) break;
             }
         }
-        float tw = ta;                                          // streaming walk position
-        int walked = 0;
-        bool walk_done = false;
+        int wcx, wcy, walked = 0;                               // streaming walk
+        walk_start(wcx, wcy);
+        bool wfin = false;
         for (;;) {
             int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
             if (stream) {
-                // next occupied cell along the ray (a cell met twice in a row -- the eps nudges -- is taken once)
-                while (!walk_done && walked < max_cells) {
-                    const int cell = cell_at(tw);
+                // next occupied cell along the ray (ranks ascend)
+                while (!wfin && walked < max_cells) {
+                    const int cell = walk_step(wcx, wcy, wfin);
                     ++walked;
-                    if (!(tw < tb)) walk_done = true;
                     if (cell >= 0 && occ[cell] >= 0) { const int r = rank[cell]; if (r > last) { best_r = r; best_cell = cell; break; } }
                 }
             } else {
                 // select the next occupied cell of this slab: rank ascending = near -> far (descending for the literal OVER order)
-                float t = ta;
-                for (int guard = 0; guard < max_cells; ++guard) {
-                    const int cell = cell_at(t);
+                int cx, cy;
+                walk_start(cx, cy);
+                bool fin = false;
+                for (int guard = 0; guard < max_cells && !fin; ++guard) {
+                    const int cell = walk_step(cx, cy, fin);
                     if (cell >= 0 && occ[cell] >= 0) {
                         const int r = rank[cell];
                         const bool better = over ? (r < last && r > best_r) : (r > last && r < best_r);
                         if (better) { best_r = r; best_cell = cell; }
                     }
-                    if (!(t < tb)) break;
                 }
             }
             if (best_cell < 0) break;
