@@ -8,6 +8,7 @@ import sys
 import time
 
 import numpy as np
+import torch    # before libvpfx: torch ships its own HIP runtime, and the first one loaded must be the one both use
 
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package; load_package()
@@ -79,6 +80,41 @@ def one_case(seed):
     so, sg = o.stats()["samples"], g.stats()["samples"]
     assert so == sg, f"samples {so} vs {sg}"                       # every lattice sample of the oracle, none more
     assert ge.stats()["samples"] <= sg
+    # every third case: the slab-sharded path (K engines on this GPU, in-process exchanges) and the literal-order kernel
+    if seed % 3 == 0 and sc.N[2] >= 2:
+        from vpfx_amd import parallel as PAR, abi
+        world = int(rng.integers(2, min(sc.N[2], 4) + 1))
+        bounds = PAR.slab_bounds(sc.N[2], world)
+        engs = []
+        for r in range(world):
+            e = E.Engine(sc.config(device=0, slab=bounds[r]), exact=exact, early_out=bool(rng.integers(0, 2)))
+            e.set_frame(sc.light_to_world, sc.grid_center)
+            e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+            engs.append(PAR.HipSlabEngine(e, torch.device("cuda", 0)))
+        taus = []
+        for h in engs:
+            h.bin_resident()
+            taus.append(h.fill_local(sc.fill_params()).clone())
+        for r, h in enumerate(engs):
+            t_in = None
+            for j in range(r):
+                t_in = taus[j].clone() if t_in is None else t_in.mul_(taus[j])
+            h.fill_finish(t_in)
+        plan, _ = PAR.blend_plan(bounds, engs[0].z_boundary(cam))
+        parts = {}
+        for r, h in enumerate(engs):
+            over, under = h.raymarch_partial(cam, rp)
+            parts[(r, "over")], parts[(r, "under")] = over.clone(), under.clone()
+        img = engs[0].blend([parts[(r, w)] for r, w, _ in plan], [kk for _, _, kk in plan]).cpu().numpy()
+        err_s = float(np.abs(img - io).max())
+        assert err_s <= 1e-3, f"slabs({world}) rgba {err_s}"
+        np.testing.assert_allclose(engs[-1].e.read_lightmap(), o.read_lightmap(), rtol=2e-5, atol=1e-9)
+        for h in engs:
+            h.e.close()
+        rq = sc.raymarch_params()
+        rq.flags = abi.VP_RM_QUANTIZE_UNORM8
+        iq_o, iq_g = o.raymarch(cam, rq), g.raymarch(cam, rq)
+        assert float(np.abs(iq_o - iq_g).max()) <= 1.01 / 255, "unorm8 emulation"
     for x in (g, ge):
         x.close()
     return dict(N=sc.N, nv=nv, P=P, border=border, occupied=int(o.stats()["occupied_mv"]), samples=int(so), zb=int(o.z_boundary(cam)),

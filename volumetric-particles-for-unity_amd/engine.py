@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -23,6 +24,22 @@ class VpfxError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  One process must use ONE HIP runtime: if libvpfx
+    pulled in /opt/rocm's copy first, a later `import torch` finds no GPU.  So when torch is installed (not necessarily imported
+    yet) its runtime is loaded first and libvpfx's NEEDED libamdhip64.so.7 resolves to it by SONAME.  No torch: nothing to do."""
+    if "torch" in sys.modules or os.environ.get("VPFX_NO_TORCH_HIP_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+        if cand and os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:       # a broken torch install must not break the binding
+        pass
+
+
 def lib():
     """Load libvpfx.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
@@ -31,6 +48,7 @@ def lib():
             raise FileNotFoundError(
                 f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.vp_last_error.restype = C.c_char_p
         L.vp_last_error.argtypes = [C.c_void_p]
