@@ -24,9 +24,9 @@ def rand_quat(rng):
 
 def one_case(seed):
     rng = np.random.default_rng(seed)
-    nv = int(rng.choice([16, 16, 32]))
-    N = int(rng.integers(1, 7 if nv == 16 else 5))
-    P = int(rng.integers(0, 500))
+    nv = int(rng.choice([16, 16, 16, 32, 32, 64]))
+    N = int(rng.integers(1, {16: 7, 32: 5, 64: 3}[nv]))
+    P = int(rng.integers(0, 500)) if rng.random() < 0.85 else int(rng.integers(500, 4000))
     W, H = int(rng.integers(17, 140)), int(rng.integers(9, 100))
     border = int(rng.choice([0, 1, 1, 2]))
     lo = rng.uniform(0.3, 1.2)
@@ -114,7 +114,10 @@ def one_case(seed):
         rq = sc.raymarch_params()
         rq.flags = abi.VP_RM_QUANTIZE_UNORM8
         iq_o, iq_g = o.raymarch(cam, rq), g.raymarch(cam, rq)
-        assert float(np.abs(iq_o - iq_g).max()) <= 1.01 / 255, "unorm8 emulation"
+        # re-quantising after every blend is discontinuous: a 1e-7 difference in front of a rounding threshold flips one 8-bit
+        # step, a later blend can turn that into two; anything beyond that, or more than a few such pixels, is a real mismatch
+        dq = np.abs(iq_o - iq_g).max(axis=-1)
+        assert float(dq.max()) <= 2.01 / 255 and int((dq > 1.01 / 255).sum()) <= 3, f"unorm8 emulation {dq.max() * 255:.2f} steps"
     for x in (g, ge):
         x.close()
     return dict(N=sc.N, nv=nv, P=P, border=border, occupied=int(o.stats()["occupied_mv"]), samples=int(so), zb=int(o.z_boundary(cam)),
