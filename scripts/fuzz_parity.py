@@ -29,7 +29,7 @@ def one_case(seed):
     P = int(rng.integers(0, 500)) if rng.random() < 0.85 else int(rng.integers(500, 4000))
     W, H = int(rng.integers(17, 140)), int(rng.integers(9, 100))
     border = int(rng.choice([0, 1, 1, 2]))
-    lo = rng.uniform(0.3, 1.2)
+    lo = rng.uniform(0.3, 1.2) if rng.random() < 0.9 else rng.uniform(2.0, 6.0)      # now and then particles larger than a metavoxel
     sc = S.make_scene("fuzz", seed=seed, dims=(N, nv, P, W, H), border=border, fade=int(rng.integers(0, 2)),
                       size_range=(lo, lo + rng.uniform(0.1, 1.2)), rotation_in_radians=bool(rng.integers(0, 2)))
     if rng.random() < 0.5:      # non-cubic grid
