@@ -22,7 +22,8 @@ def rand_quat(rng):
     return tuple(q)            # (x, y, z, w)
 
 
-def one_case(seed):
+def make_case_scene(seed):
+    """The random scene of one case; returns (scene, rng) with rng positioned for the engine options."""
     rng = np.random.default_rng(seed)
     nv = int(rng.choice([16, 16, 16, 32, 32, 64]))
     N = int(rng.integers(1, {16: 7, 32: 5, 64: 3}[nv]))
@@ -57,6 +58,13 @@ def one_case(seed):
         sd = np.full((H, W), 1.0e30, dtype=np.float32)
         sd[: H // 2] = np.float32(D * rng.uniform(0.3, 1.2))
         sc.scene_depth = sd
+    return sc, rng
+
+
+def one_case(seed):
+    sc, rng = make_case_scene(seed)
+    nv, P, border = sc.nv, len(sc.particles), sc.border
+    cam, rp = None, None
     exact = bool(rng.integers(0, 2))
     o = O.Oracle(sc.config())
     g = E.Engine(sc.config(), exact=exact, early_out=False)
