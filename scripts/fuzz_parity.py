@@ -126,6 +126,23 @@ def one_case(seed):
         # step, a later blend can turn that into two; anything beyond that, or more than a few such pixels, is a real mismatch
         dq = np.abs(iq_o - iq_g).max(axis=-1)
         assert float(dq.max()) <= 2.01 / 255 and int((dq > 1.01 / 255).sum()) <= 3, f"unorm8 emulation {dq.max() * 255:.2f} steps"
+    # a second frame on the SAME contexts: other particles, other camera -- stale bins / bricks / light map would show here
+    if seed % 2 == 0 and len(sc.particles) > 4:
+        keep = rng.random(len(sc.particles)) < 0.6
+        sc.particles = sc.particles[keep].copy()
+        sc.particles["position"] += rng.normal(scale=0.8, size=(len(sc.particles), 3)).astype(np.float32)
+        d2 = rng.normal(size=3)
+        d2 /= np.linalg.norm(d2)
+        sc.set_camera(tuple(d2 * 0.8 * max(sc.N) * sc.mv_scale * rng.uniform(0.3, 1.3) + np.asarray(sc.grid_center, dtype=np.float64)),
+                      target=tuple(np.asarray(sc.grid_center, dtype=np.float64)))
+        cam2, rp2 = sc.camera(), sc.raymarch_params()
+        for x in (o, g):
+            x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+            x.fill(sc.fill_params())
+        assert np.array_equal(o.bin_counts(), g.bin_counts()), "frame 2: bin counts"
+        np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+        i2o, i2g = o.raymarch(cam2, rp2), g.raymarch(cam2, rp2)
+        assert float(np.abs(i2o - i2g).max()) <= 1e-3 and o.stats()["samples"] == g.stats()["samples"], "frame 2"
     for x in (g, ge):
         x.close()
     return dict(N=sc.N, nv=nv, P=P, border=border, occupied=int(o.stats()["occupied_mv"]), samples=int(so), zb=int(o.z_boundary(cam)),
