@@ -7,8 +7,8 @@
 //
 // CDNA4 shape: a wave owns an 8x8 pixel tile (neighbouring rays hit the same bricks -> L1/L2 reuse; the final
 // float4 store is eight 128-byte lines).  Each thread sets its ray up once in "grid space" (MV (x,y,z) spans
-// [x,x+1)^3, light-aligned), then walks the light-axis slabs zz ascending -- the reference's major draw order
-// for both phases -- and inside a slab visits the (x,y) cells its ray crosses in the reference's sorted order
+// [x,x+1)^3, light-aligned), then walks the light-axis slabs -- zz is the reference's major draw order in both
+// phases -- and inside a slab visits the (x,y) cells its ray crosses (integer DDA) in the reference's sorted order
 // (rank table built on the host from the same keys as SortMetavoxelSlicesFarToNearFromEye).  Per MV it runs the
 // reference's back-to-front sample loop with software trilinear filtering of the RGBA16F brick (no image
 // hardware on gfx950) and blends in registers, front to back (the reverse of the reference's OVER phase, then its UNDER
