@@ -49,8 +49,13 @@ int ensure_bricks(vp_ctx* c, bool need_scratch)
         if (c->d_bricks) VP_HIP(hipFree(c->d_bricks));
         c->d_bricks = nullptr;
         c->brick_cap = 0;
-        const size_t cap = need + need / 8 + 16;
-        VP_HIP(hipMalloc((void**)&c->d_bricks, cap * nv3(c) * sizeof(uint2)));
+        size_t cap = need + need / 8 + 16;               // head-room so that a slowly growing cloud does not reallocate every frame
+        if (hipMalloc((void**)&c->d_bricks, cap * nv3(c) * sizeof(uint2)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_bricks = nullptr;
+            cap = need;                                    // ... but an exact fit beats failing (config 5 is 157 GiB of bricks)
+            VP_HIP(hipMalloc((void**)&c->d_bricks, cap * nv3(c) * sizeof(uint2)));
+        }
         c->brick_cap = cap;
     }
     if (need_scratch && need > c->dens_cap) {
