@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--exchange", default="tiles", choices=["tiles", "all_gather"],
                     help="N > 1 image exchange: all-to-all of screen pieces + sharded blend (default) or one all-gather of whole partial images")
     ap.add_argument("--uniform-slabs", action="store_true", help="equal-thickness slabs instead of pair-count balanced ones")
+    ap.add_argument("--no-reference-frame", action="store_true", help="N > 1: do not render the 1-GPU frame on rank 0 for the shard check")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,30 +92,45 @@ def main():
             dist.init_process_group(args.backend)
 
     sc = S.make_scene(args.config)
-    weights = None
-    if world > 1 and not args.uniform_slabs:
-        # balanced slabs: every rank computes the same (particle, MV)-pair histogram along the light axis
+    weights, whole_occupied = None, None
+    if world > 1:
+        # every rank computes the same (particle, MV)-pair histogram along the light axis (balanced slabs) and the
+        # whole-grid occupancy (sizes the optional 1-GPU reference frame below); binning allocates no bricks
         probe = E.Engine(sc.config(device=local_rank))
         probe.set_frame(sc.light_to_world, sc.grid_center)
         probe.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
-        weights = [float(x) for x in probe.z_histogram()]
+        if not args.uniform_slabs:
+            weights = [float(x) for x in probe.z_histogram()]
+        probe.bin_resident()
+        whole_occupied = probe.stats()["occupied_mv"]
         probe.close()
     bounds = PAR.slab_bounds(sc.N[2], world, weights)
     # strong scaling: the unit of work is the SINGLE-GPU job (its voxels and its executed samples).  Sharded runs execute
     # more lattice samples in total (the saturation early-out only sees one slab), which must not inflate `value`.
-    ref_units, ref_image = None, None
+    ref_units, ref_image, ref_skipped = None, None, None
     if world > 1 and rank == 0:
-        one = E.Engine(sc.config(device=local_rank))
-        one.set_frame(sc.light_to_world, sc.grid_center)
-        one.bin(sc.particles, sc.layout, sc.psys_local_to_world)
-        one.fill(sc.fill_params())
-        ref_image = torch.empty((sc.height, sc.width, 4), device=device)
-        one.raymarch_device(sc.camera(), sc.raymarch_params(), ref_image.data_ptr())
-        one.sync()
-        st1 = one.stats()
-        ref_units = (st1["voxels_filled"], st1["samples"])
-        one.close()
-        torch.cuda.empty_cache()
+        # The 1-GPU reference frame is rendered on rank 0 only if the whole grid's brick pool fits NEXT TO this rank's slab
+        # engine (bricks + 16 B/voxel split-fill scratch): at config 5 it is ~190 GB and must not be attempted.
+        brick = 8 * sc.nv ** 3
+        need_ref = whole_occupied * brick * 1.125 + 2e9
+        need_slab = 3.0 * (whole_occupied / world) * 1.5 * brick * 1.125 + 2e9      # bricks + 2x scratch, 1.5x for an uneven slab
+        free, _ = torch.cuda.mem_get_info()
+        if need_ref + need_slab > 0.9 * free or args.no_reference_frame:
+            ref_skipped = (f"1-GPU reference frame skipped: whole-grid brick pool {need_ref / 1e9:.0f} GB + slab engine "
+                           f"{need_slab / 1e9:.0f} GB vs {free / 1e9:.0f} GB free" if not args.no_reference_frame else "--no-reference-frame")
+            print(f"[bench] {ref_skipped}", file=sys.stderr)
+        else:
+            one = E.Engine(sc.config(device=local_rank))
+            one.set_frame(sc.light_to_world, sc.grid_center)
+            one.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+            one.fill(sc.fill_params())
+            ref_image = torch.empty((sc.height, sc.width, 4), device=device)
+            one.raymarch_device(sc.camera(), sc.raymarch_params(), ref_image.data_ptr())
+            one.sync()
+            st1 = one.stats()
+            ref_units = (st1["voxels_filled"], st1["samples"])
+            one.close()
+            torch.cuda.empty_cache()
     eng = E.Engine(sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0)))
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
@@ -213,9 +229,10 @@ def main():
                        "parallelism": f"zslab{world}" + (f" ({args.exchange} exchange)" if world > 1 else ""), "slabs": bounds if world > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),
-                       "work_unit": "voxels + executed samples of the 1-GPU job (fixed for every N)",
+                       "work_unit": ("voxels + executed samples of the 1-GPU job (fixed for every N)" if (world == 1 or ref_units is not None)
+                                     else "voxels + samples executed on all ranks (1-GPU reference job not run: see reference_frame_skipped)"),
                        "samples_executed_all_ranks": int(executed[1]),
-                       "max_abs_rgba_diff_vs_1gpu_frame": shard_err},
+                       "max_abs_rgba_diff_vs_1gpu_frame": shard_err, "reference_frame_skipped": ref_skipped},
             # absolute rates: per stage against that stage's kernel time on the slowest rank (fill = local + finish for N > 1),
             # and for the whole frame (everything incl. the exchanges)
             "fill_mvoxels_per_s": voxels / ((smax[1] + smax[3]) * 1e-3) / 1e6,

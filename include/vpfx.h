@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VPFX_ABI_VERSION 1
+#define VPFX_ABI_VERSION 2   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view */
 
 typedef enum vp_status {
     VP_OK = 0,
@@ -84,12 +84,23 @@ typedef struct vp_fill_params {
     float   light_near, light_far;/* light camera clip planes (0.3 / 1000, VPR.cs:340-342)        */
     float   light_cam_distance;   /* light camera sits gridCenter - fwd*200 (VPR.cs:365)          */
     int32_t cubemap_size;         /* S: edge of one displacement cubemap face                     */
-    int32_t reserved;
-    const float* cubemap;         /* 6*S*S f32 = .x channel of _DisplacementTexture; faces in D3D
-                                     order +X,-X,+Y,-Y,+Z,-Z; row 0 = top; bilinear, clamp        */
+    int32_t cubemap_format;       /* VP_CUBEMAP_F32 (0) or VP_CUBEMAP_R8 (1)                       */
+    const void* cubemap;          /* 6*S*S texels = .x channel of _DisplacementTexture; faces in D3D
+                                     order +X,-X,+Y,-Y,+Z,-Z; row 0 = top; bilinear, clamp.
+                                     F32: floats in [0,1].  R8: bytes, texel = byte/255 (UNORM) -- the
+                                     reference's own asset is 8-bit (ARGB32, Assets/Textures/
+                                     DisplacementTexture.cubemap:10-23, bound FillVolume.mat:23-29).
+                                     NULL = keep the cube map of the previous vp_fill resident.
+                                     displacement_scale must lie in [0,1] (the reference's slider,
+                                     scene:8103-8111) and every texel in [0,1]: netDisplacement >= 0
+                                     is what Fill.shader:119-126 assumes; anything else is refused
+                                     with VP_ERR_BAD_ARG                                           */
     const float* light_depth_map; /* optional [(Ny*nv)][(Nx*nv)] f32 in [0,1] (_LightDepthMap,
                                      D3D ortho depth); NULL = 1.0 everywhere (no occluders)       */
 } vp_fill_params;
+
+#define VP_CUBEMAP_F32 0
+#define VP_CUBEMAP_R8  1
 
 /* Main camera: SetRaymarchPassConstants (VPR.cs:733-737) + RenderMetavoxel (VPR.cs:778). */
 typedef struct vp_camera {
@@ -114,6 +125,9 @@ typedef struct vp_raymarch_params {
                                      re-quantised to UNORM8 after every metavoxel blend.  Default: fp32 */
 #define VP_RM_SHOW_NUM_SAMPLES 2  /* _ShowNumSamples debug view: colour-code the samples taken per metavoxel (RM.shader:283-299) */
 #define VP_RM_SHOW_BLEND_FUNC  4  /* _ShowRayMarchBlendFunc debug view: yellow = OVER, cyan = UNDER (RM.shader:174-181)        */
+#define VP_RM_SHOW_DRAW_ORDER  8  /* _ShowMetavoxelDrawOrder debug view: every metavoxel coloured by its position in the global
+                                     submission order (DrawOrderColoring, RM.shader:123-138, 170-173; _OrderIndex = mvCount of
+                                     VPR.cs:650-706, _NumMetavoxelsCovered VPR.cs:755).  Whole-grid contexts only               */
 
 /* An opaque occluder: oriented box (the demo scene's ground/back planes and cubes are boxes).  Used to PRODUCE the two
  * scene-occlusion inputs of the path on the GPU instead of reading them back from Unity render targets:
@@ -174,6 +188,18 @@ int  vp_bin_resident(vp_ctx* ctx);
 /* FillMetavoxels / FillMetavoxel + FillVolume.shader (VPR.cs:495-609, Fill.shader:152-274). */
 int  vp_fill(vp_ctx* ctx, const vp_fill_params* params);
 
+/* The reference's per-metavoxel entry point FillMetavoxel(xx, yy, zz) (VPR.cs:559-609), for callers that drive the fill
+ * themselves (debugging one metavoxel, partial refills):
+ *   vp_fill_begin      = the head of FillMetavoxels: SetFillPassConstants + clear of lightPropogationTex to 1.0
+ *                        (VPR.cs:497-503, 523-554); same params as vp_fill
+ *   vp_fill_metavoxel  = FillMetavoxel: fills ONE metavoxel's brick from its particle list, reading the light that
+ *                        reaches it from the light-propagation map and writing the transmitted light back
+ *                        (Fill.shader:224, 250).  An empty metavoxel is a no-op (the reference never calls it for one,
+ *                        VPR.cs:511).  Calling it for every occupied metavoxel in zz-major order after vp_fill_begin
+ *                        reproduces vp_fill bit for bit. */
+int  vp_fill_begin(vp_ctx* ctx, const vp_fill_params* params);
+int  vp_fill_metavoxel(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz);
+
 /* RenderMetavoxels / RenderMetavoxel + RayMarchVoxel.shader + ROP blend
  * (VPR.cs:613-794, RM.shader:14-18,95-302).  rgba_out = particlesRT as [H][W][4] f32.
  * vp_raymarch synchronises and copies to host; the _device form writes device memory and is
@@ -181,6 +207,20 @@ int  vp_fill(vp_ctx* ctx, const vp_fill_params* params);
 int  vp_raymarch(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, float* rgba_out);
 int  vp_raymarch_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params,
                         void* d_rgba_out);
+
+/* The reference's per-metavoxel entry point RenderMetavoxel(xx, yy, zz, orderIndex) (VPR.cs:766-794) on the context's own
+ * particlesRT (VPR.cs:228), with the blend state RenderMetavoxels sets around it (VPR.cs:659-662 / 688-691):
+ *   vp_clear_particles_rt  = OnPreRender: GL.Clear(particlesRT, (0,0,0,0))                         VPR.cs:168-177
+ *   vp_render_metavoxel    = one DrawMeshNow(cube): every pixel whose ray hits the metavoxel marches it and blends the
+ *                            result into particlesRT; blend_over = 1: Blend One OneMinusSrcAlpha, 0: Blend OneMinusDstAlpha One.
+ *                            order_index is only read by the VP_RM_SHOW_DRAW_ORDER view (_OrderIndex).  Empty MV: no-op.
+ *   vp_read_particles_rt   = read particlesRT back, [H][W][4] f32.
+ * Submitting every occupied metavoxel in the order of RenderMetavoxels reproduces vp_raymarch (up to fp32 rounding of the
+ * blend association, ~1e-7; exactly with VP_RM_QUANTIZE_UNORM8 off and the literal order of the flags kernel). */
+int  vp_clear_particles_rt(vp_ctx* ctx);
+int  vp_render_metavoxel(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, int32_t xx, int32_t yy, int32_t zz,
+                         int32_t blend_over, int32_t order_index);
+int  vp_read_particles_rt(vp_ctx* ctx, float* rgba_out);
 
 /* CompositeParticles.shader (Comp.shader:10, VPR.cs:210): scene.rgb = p.rgb + scene.rgb*(1-p.a),
  * scene.a += p.a; in place on device images [H][W][4] f32. */

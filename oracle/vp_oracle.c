@@ -589,7 +589,13 @@ static int retain_fill_params(vpo_ctx* c, const vp_fill_params* p)
     free(c->cubemap); free(c->depthmap); c->depthmap = NULL;
     size_t cn = (size_t)6 * p->cubemap_size * p->cubemap_size;
     c->cubemap = (float*)malloc(cn * sizeof(float));
-    memcpy(c->cubemap, p->cubemap, cn * sizeof(float));
+    if (p->cubemap_format == VP_CUBEMAP_R8) {
+        /* 8-bit UNORM texels (the reference's asset, DisplacementTexture.cubemap:10-23): D3D11 UNORM -> float = byte / 255 */
+        const unsigned char* b = (const unsigned char*)p->cubemap;
+        for (size_t i = 0; i < cn; ++i) c->cubemap[i] = (float)b[i] / 255.0f;
+    } else {
+        memcpy(c->cubemap, p->cubemap, cn * sizeof(float));
+    }
     c->cube_s = p->cubemap_size;
     if (p->light_depth_map) {
         size_t dn = (size_t)c->Nx * c->nv * c->Ny * c->nv;
@@ -1093,6 +1099,13 @@ static int raymarch_impl(vpo_ctx* c, const vp_camera* cam, const vp_raymarch_par
                     if (k.flags & VP_RM_SHOW_BLEND_FUNC) {                     /* debug view          RM.shader:174-181 */
                         if (kind[i] == 0) { src[0] = 0.5f; src[1] = 0.5f; src[2] = 0.f; src[3] = 1.f; }
                         else { src[0] = 0.f; src[1] = 0.5f; src[2] = 0.5f; src[3] = 1.f; }
+                    }
+                    if (k.flags & VP_RM_SHOW_DRAW_ORDER) {                     /* DrawOrderColoring   RM.shader:123-138,170-173 */
+                        int per = (int)ceilf((float)c->occupied / 3.0f);       /* _NumMetavoxelsCovered VPR.cs:755; _OrderIndex = i */
+                        if (per < 1) per = 1;
+                        int sel = i / per, idx = i % per;
+                        float v = (float)(per - idx) / (float)per;
+                        src[0] = sel >= 2 ? v : 0.f; src[1] = sel == 0 ? v : 0.f; src[2] = sel == 1 ? v : 0.f; src[3] = 1.f;
                     }
                     float* dst = img + ((size_t)row * c->W + col) * 4;
                     if (kind[i] == 0) {        /* Blend One OneMinusSrcAlpha (all channels)      VPR.cs:659-662 */

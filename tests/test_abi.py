@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = E.lib()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.vp_abi_version() == 1
+    assert lib.vp_abi_version() == abi.VPFX_ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header():
@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(vp_config), sizeof(vp_particle_layout), sizeof(vp_fill_params), sizeof(vp_camera),
          sizeof(vp_raymarch_params), sizeof(vp_stats));
-  printf("%zu %zu %zu %zu\n", offsetof(vp_fill_params, cubemap), offsetof(vp_fill_params, light_depth_map),
+  printf("%zu %zu %zu %zu %zu\n", offsetof(vp_fill_params, cubemap), offsetof(vp_fill_params, light_depth_map), offsetof(vp_fill_params, cubemap_format),
          offsetof(vp_raymarch_params, scene_depth), offsetof(vp_camera, fov_y));
   return 0; }
 '''
@@ -52,7 +52,7 @@ int main(void) {
     sizes = [int(x) for x in out]
     mirror = [C.sizeof(abi.vp_config), C.sizeof(abi.vp_particle_layout), C.sizeof(abi.vp_fill_params), C.sizeof(abi.vp_camera),
               C.sizeof(abi.vp_raymarch_params), C.sizeof(abi.vp_stats),
-              abi.vp_fill_params.cubemap.offset, abi.vp_fill_params.light_depth_map.offset,
+              abi.vp_fill_params.cubemap.offset, abi.vp_fill_params.light_depth_map.offset, abi.vp_fill_params.cubemap_format.offset,
               abi.vp_raymarch_params.scene_depth.offset, abi.vp_camera.fov_y.offset]
     assert sizes == mirror
 

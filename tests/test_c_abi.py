@@ -95,7 +95,7 @@ def test_demo_frame_matches_the_python_binding_and_the_oracle(tmp_path):
     fp.opacity_factor, fp.displacement_scale = 0.04, 0.7
     fp.ambient[0] = fp.ambient[1] = fp.ambient[2] = 0.2
     fp.init_light_intensity, fp.light_near, fp.light_far, fp.light_cam_distance = 1.0, 0.3, 1000.0, 200.0
-    fp.cubemap_size, fp.cubemap = 16, cube.ctypes.data_as(abi.c_float_p)
+    abi.set_cubemap(fp, cube)
     D = np.float32(0.8 * N * 3.0)
     cam = abi.vp_camera()
     m = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, -1, 0, 0, 0, -float(D), 1]

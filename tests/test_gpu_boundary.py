@@ -1,0 +1,224 @@
+"""GPU: the drop-in boundary items of SURVEY 8(b) added in round 2, all through the C ABI, all against the oracle:
+R8 displacement cube maps, refusal of out-of-range displacement inputs, the reference's per-metavoxel entry points
+FillMetavoxel(xx,yy,zz) / RenderMetavoxel(xx,yy,zz,orderIndex), and the _ShowMetavoxelDrawOrder view."""
+import numpy as np
+import pytest
+
+from vpfx_amd import abi, engine as E, scene as S
+from vpfx_amd.manager import MetavoxelManager
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def both(sc, **kw):
+    o, g = O.Oracle(sc.config()), E.Engine(sc.config(), **kw)
+    for x in (o, g):
+        x.set_frame(sc.light_to_world, sc.grid_center)
+        x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        x.fill(sc.fill_params())
+    return o, g
+
+
+def r8_cubemap(size=32, seed=5):
+    rng = np.random.default_rng(seed)
+    c = rng.integers(0, 256, size=(6, size, size), dtype=np.uint8)
+    c[0, :4, :4] = 0            # exercise both ends of the UNORM range
+    c[1, :4, :4] = 255
+    return np.ascontiguousarray(c)
+
+
+@pytest.mark.parametrize("D", [0.7, 1.0, 0.0])
+def test_r8_cubemap_matches_the_oracle_fed_the_same_bytes(D):
+    """The reference's displacement texture is 8-bit (DisplacementTexture.cubemap:10-23): bytes in, texel = byte/255.
+    D = 1 with zero texels makes netDisplacement exactly 0 (smoothstep edges collapse): still the oracle's bricks."""
+    sc = S.make_scene("T0")
+    sc.cubemap = r8_cubemap()
+    sc.displacement_scale = D
+    o, g = both(sc, exact=True, early_out=False)
+    cnt = o.bin_counts()
+    np.testing.assert_array_equal(cnt, g.bin_counts())
+    for zz, yy, xx in zip(*np.nonzero(cnt)):
+        a, b = o.read_brick(xx, yy, zz).view(np.uint16), g.read_brick(xx, yy, zz).view(np.uint16)
+        assert np.array_equal(a, b), (xx, yy, zz)
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ig).max() <= 1e-3
+    # ... and the same bytes handed over as floats are the same frame: the R8 path is only a format
+    sc2 = S.make_scene("T0")
+    sc2.cubemap = np.ascontiguousarray(sc.cubemap.astype(np.float32) / np.float32(255.0))
+    sc2.displacement_scale = D
+    g2 = E.Engine(sc2.config(), exact=True, early_out=False)
+    g2.set_frame(sc2.light_to_world, sc2.grid_center)
+    g2.bin(sc2.particles, sc2.layout, sc2.psys_local_to_world)
+    g2.fill(sc2.fill_params())
+    np.testing.assert_array_equal(g2.raymarch(sc2.camera(), sc2.raymarch_params()), ig)
+
+
+def test_r8_cubemap_default_math_within_one_fp16_ulp():
+    sc = S.make_scene("T0")
+    sc.cubemap = r8_cubemap(64, 9)
+    o, g = both(sc)
+    cnt = o.bin_counts()
+    for zz, yy, xx in zip(*np.nonzero(cnt)):
+        a, b = o.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32), g.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32)
+        assert np.abs(a - b).max() <= 1, (xx, yy, zz)
+
+
+def test_out_of_range_displacement_inputs_are_refused():
+    """netDisplacement = D raw + (1 - D) >= 0 is what Fill.shader:119-126 assumes (slider [0,1], scene:8103-8111)."""
+    sc = S.make_scene("T0")
+    g = E.Engine(sc.config())
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    for D in (1.5, -0.1, float("nan")):
+        sc.displacement_scale = D
+        with pytest.raises(E.VpfxError) as ei:
+            g.fill(sc.fill_params())
+        assert ei.value.code == abi.VP_ERR_BAD_ARG and "displacement_scale" in str(ei.value)
+    sc.displacement_scale = 0.7
+    good = sc.cubemap
+    for bad_value in (1.25, -0.01, np.nan):
+        sc.cubemap = good.copy()
+        sc.cubemap[3, 5, 7] = bad_value
+        with pytest.raises(E.VpfxError) as ei:
+            g.fill(sc.fill_params())
+        assert ei.value.code == abi.VP_ERR_BAD_ARG and "texels" in str(ei.value)
+        # the refused map is not resident either
+        fp = sc.fill_params()
+        fp.cubemap = None
+        with pytest.raises(E.VpfxError):
+            g.fill(fp)
+    fp = sc.fill_params()
+    fp.cubemap_format = 7
+    with pytest.raises(E.VpfxError):
+        g.fill(fp)
+    sc.cubemap = good
+    g.fill(sc.fill_params())                       # and a good map afterwards works
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
+
+
+def _manager(sc):
+    m = MetavoxelManager(sc.N[0], sc.N[1], sc.N[2], sc.mv_scale, sc.nv, sc.border, sc.width, sc.height)
+    m.Start()
+    m.SetLight(sc.light_to_world)
+    m.SetGridCenter(sc.grid_center)
+    m.psysLocalToWorld = sc.psys_local_to_world
+    m.SetDisplacementTexture(sc.cubemap)
+    return m
+
+
+@pytest.mark.parametrize("cam_pos", [None, (-9.0, 2.0, 1.0), (2.0, 6.0, -1.0)])
+def test_per_metavoxel_entry_points_replay_the_reference_loops(cam_pos):
+    """FillMetavoxel(xx,yy,zz) for every occupied MV in zz-major order (VPR.cs:505-518) == FillMetavoxels;
+    RenderMetavoxel(xx,yy,zz,i) in the submission order of RenderMetavoxels (VPR.cs:652-711) == RenderMetavoxels == oracle."""
+    sc = S.make_scene("T0")
+    if cam_pos is not None:
+        sc.set_camera(cam_pos)                     # zBoundary inside the grid: OVER and UNDER draws
+    cam = sc.camera()
+    m = _manager(sc)
+    m.BinParticlesToMetavoxels(sc.particles, sc.layout)
+    m.FillMetavoxels()
+    e = m._engine
+    cnt = e.bin_counts()
+    bricks = {k: e.read_brick(k[2], k[1], k[0]).copy() for k in zip(*np.nonzero(cnt))}
+    lm = e.read_lightmap()
+    frame = m.RenderMetavoxels(cam)
+    n_cov = m.numMetavoxelsCovered
+    # the literal per-draw fill
+    m.FillMetavoxelsPerDraw()
+    assert m.numMetavoxelsCovered == n_cov == int((cnt != 0).sum())
+    for k, b in bricks.items():
+        assert np.array_equal(e.read_brick(k[2], k[1], k[0]).view(np.uint16), b.view(np.uint16)), k
+    np.testing.assert_array_equal(e.read_lightmap(), lm)
+    # the literal per-draw render
+    per_draw = m.RenderMetavoxelsPerDraw(cam)
+    assert np.abs(per_draw - frame).max() <= 2e-6          # same blends, associated the other way round
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    io = o.raymarch(cam, sc.raymarch_params())
+    assert np.abs(per_draw - io).max() <= 1e-3
+    assert e.stats()["samples"] == o.stats()["samples"]    # the per-draw kernel executes the oracle's samples
+    zb = e.z_boundary(cam)
+    assert (zb >= 0) == (cam_pos is not None)
+
+
+def test_fill_one_metavoxel_only_touches_that_metavoxel():
+    sc = S.make_scene("T0")
+    m = _manager(sc)
+    m.BinParticlesToMetavoxels(sc.particles, sc.layout)
+    m.FillMetavoxels()
+    e = m._engine
+    cnt = e.bin_counts()
+    occ = list(zip(*np.nonzero(cnt)))
+    zz, yy, xx = occ[len(occ) // 2]
+    before = {k: e.read_brick(k[2], k[1], k[0]).copy() for k in occ}
+    lm0 = e.read_lightmap()
+    # refill that one MV with another opacity factor: only its brick changes, and only its light-map footprint
+    m.SetOpacityFactor(0.08)
+    m.FillMetavoxelsBegin()
+    m.FillMetavoxel(xx, yy, zz)
+    changed = [k for k in occ if not np.array_equal(e.read_brick(k[2], k[1], k[0]).view(np.uint16), before[k].view(np.uint16))]
+    assert changed == [(zz, yy, xx)]
+    lm = e.read_lightmap()
+    nv = sc.nv
+    mask = np.zeros_like(lm, dtype=bool)
+    mask[yy * nv:(yy + 1) * nv, xx * nv:(xx + 1) * nv] = True
+    np.testing.assert_array_equal(lm[~mask], 1.0)          # cleared to 1 by vp_fill_begin, untouched elsewhere
+    assert (lm[mask] < 1.0).any() and lm0.shape == lm.shape
+    # empty metavoxel: a no-op, not an error (the reference never submits one, VPR.cs:511)
+    ez, ey, ex = [int(v[0]) for v in np.nonzero(cnt == 0)]
+    m.FillMetavoxel(ex, ey, ez)
+    with pytest.raises(E.VpfxError):
+        m.FillMetavoxel(sc.N[0], 0, 0)
+
+
+@pytest.mark.parametrize("cam_pos", [None, (3.0, 30.0, 2.0)])
+def test_draw_order_view_matches_the_oracle(cam_pos):
+    """_ShowMetavoxelDrawOrder (RM.shader:123-138, 170-173): the regression guard for the global submission order."""
+    sc = S.make_scene("C1")
+    if cam_pos is not None:
+        sc.set_camera(cam_pos)
+    o, g = both(sc)
+    rp = sc.raymarch_params()
+    rp.flags = abi.VP_RM_SHOW_DRAW_ORDER
+    io, ig = o.raymarch(sc.camera(), rp), g.raymarch(sc.camera(), rp)
+    # opaque colours blended in order: a mismatch of ONE position in the order changes a channel by >= 1/104
+    assert np.abs(io - ig).max() <= 1e-6
+    assert len(np.unique(ig.reshape(-1, 4), axis=0)) > 50   # many distinct order colours are visible
+    # and the per-draw entry point shows the same picture when handed the same order indices
+    m = _manager(sc)
+    m.SetShowMetavoxelDrawOrder(True)
+    m.BinParticlesToMetavoxels(sc.particles, sc.layout)
+    m.FillMetavoxels()
+    assert np.abs(m.RenderMetavoxelsPerDraw(sc.camera()) - io).max() <= 1e-6
+    assert np.abs(m.RenderMetavoxels(sc.camera()) - io).max() <= 1e-6
+
+
+def test_draw_order_view_needs_the_whole_grid():
+    sc = S.make_scene("T0")
+    g = E.Engine(sc.config(slab=(0, 2)))
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    g.fill(sc.fill_params())
+    rp = sc.raymarch_params()
+    rp.flags = abi.VP_RM_SHOW_DRAW_ORDER
+    with pytest.raises(E.VpfxError) as ei:
+        g.raymarch(sc.camera(), rp)
+    assert ei.value.code == abi.VP_ERR_UNSUPPORTED
+
+
+def test_manager_first_frame_always_fills():
+    """A host whose first OnPostRender lands on a frame with frameCount % updateInterval != 0 must not ray-march unfilled textures."""
+    sc = S.make_scene("T0")
+    m = _manager(sc)
+    img = m.OnPostRender(1, sc.particles, sc.layout, sc.camera())       # updateInterval = 2, frame 1
+    m2 = _manager(sc)
+    ref = m2.OnPostRender(0, sc.particles, sc.layout, sc.camera())
+    np.testing.assert_array_equal(img, ref)

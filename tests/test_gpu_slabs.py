@@ -12,14 +12,14 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run_slabs(sc, world, cam_pos=None, weights=None):
+def run_slabs(sc, world, cam_pos=None, weights=None, **engine_kw):
     dev = torch.device("cuda", 0)
     if cam_pos is not None:
         sc.set_camera(cam_pos)
     bounds = PAR.slab_bounds(sc.N[2], world, weights)
     engs = []
     for r in range(world):
-        e = E.Engine(sc.config(device=0, slab=bounds[r]))
+        e = E.Engine(sc.config(device=0, slab=bounds[r]), **engine_kw)
         e.set_frame(sc.light_to_world, sc.grid_center)
         e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
         engs.append(PAR.HipSlabEngine(e, dev))
@@ -122,3 +122,51 @@ def test_z_histogram_matches_bin_counts_and_balances():
     single.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     single.fill(sc.fill_params())
     assert np.abs(out - single.raymarch(sc.camera(), sc.raymarch_params())).max() <= 2e-5
+
+
+# ---- BASELINE config 4: the C3 workload (32^3 x 32^3, 100k particles, 1920x1080) in 2 / 4 / 8 light-axis slabs ------------------
+@pytest.fixture(scope="module")
+def c3_reference():
+    """Single-engine C3 frame (no early-out: every lattice sample) + the oracle's frame, computed once for the three shard counts."""
+    sc = S.make_scene("C3")
+    g = E.Engine(sc.config(), early_out=False)
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+    hist = [float(x) for x in g.z_histogram()]
+    g.bin_resident()
+    g.fill(sc.fill_params())
+    frame = g.raymarch(sc.camera(), sc.raymarch_params())
+    st = g.stats()
+    lm = g.read_lightmap()
+    g.close()
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    oracle_frame = o.raymarch(sc.camera(), sc.raymarch_params())
+    oracle_samples = o.stats()["samples"]
+    o.close()
+    torch.cuda.empty_cache()
+    return dict(frame=frame, lightmap=lm, stats=st, hist=hist, oracle_frame=oracle_frame, oracle_samples=oracle_samples)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config4_c3_sharded_matches_single_engine_and_oracle(world, c3_reference):
+    """BASELINE.json configs[3]: pair-balanced slabs as bench.py --gpus N cuts them, K engines on one GPU."""
+    ref = c3_reference
+    sc = S.make_scene("C3")
+    out, lm, bounds, zb, straddler, engs = run_slabs(sc, world, weights=ref["hist"], early_out=False)
+    assert bounds[0][0] == 0 and bounds[-1][1] == 32 and all(z1 > z0 for z0, z1 in bounds)
+    loads = [sum(ref["hist"][z0:z1]) for z0, z1 in bounds]
+    assert max(loads) <= 1.35 * sum(loads) / world                      # the fill work is balanced
+    assert np.abs(out - ref["frame"]).max() <= 2e-5                     # vs the single-engine frame
+    assert np.abs(out - ref["oracle_frame"]).max() <= 1e-3              # vs the oracle (the north_star gate)
+    np.testing.assert_allclose(lm, ref["lightmap"], rtol=2e-5, atol=1e-9)
+    stats = [h.e.stats() for h in engs]
+    assert sum(s["occupied_mv"] for s in stats) == ref["stats"]["occupied_mv"] == 11325
+    assert sum(s["pairs"] for s in stats) == ref["stats"]["pairs"] == 480441
+    # every lattice sample is executed by exactly one slab: the shards partition the single-GPU work
+    assert sum(s["samples"] for s in stats) == ref["stats"]["samples"] == ref["oracle_samples"]
+    for h in engs:
+        h.e.close()
+    torch.cuda.empty_cache()

@@ -43,3 +43,41 @@ def test_blend_plan_orders_over_then_under(zb):
         assert z0 <= zb < z1 - 1 and straddler in overs and straddler in unders
     else:
         assert not (set(overs) & set(unders))
+
+
+def _check_partition(b, nz, world):
+    assert len(b) == world and b[0][0] == 0 and b[-1][1] == nz
+    assert all(z1 > z0 for z0, z1 in b), b
+    assert all(b[i][1] == b[i + 1][0] for i in range(world - 1)), b
+
+
+def test_weighted_slabs_are_always_a_valid_partition():
+    """Property test: random, one-hot, tail-heavy and head-heavy histograms, world up to nz (the round-1 repair pass pushed
+    cuts past nz: nz=8, world=4, all the work in slice 6 gave [(0,7),(7,8),(8,9),(9,8)])."""
+    import random
+    rng = random.Random(99)
+    assert PAR.slab_bounds(8, 4, [0, 0, 0, 0, 0, 0, 19250, 0]) == [(0, 5), (5, 6), (6, 7), (7, 8)]
+    for nz in (1, 2, 3, 4, 8, 16, 32, 64):
+        for world in sorted({1, 2, 3, 4, 8, nz // 2, nz - 1, nz}):
+            if world < 1 or world > nz:
+                continue
+            cases = [[0.0] * nz, [1.0] * nz, [float(i) for i in range(nz)], [float(nz - i) for i in range(nz)]]
+            for hot in range(nz):
+                cases.append([1e6 if i == hot else 0.0 for i in range(nz)])
+            for _ in range(40):
+                cases.append([rng.choice([0.0, 0.0, rng.random(), 1000.0 * rng.random()]) for _ in range(nz)])
+            for w in cases:
+                _check_partition(PAR.slab_bounds(nz, world, w), nz, world)
+    with pytest.raises(ValueError):
+        PAR.slab_bounds(8, 2, [1.0] * 7)
+
+
+def test_weighted_slabs_do_not_lose_balance_on_the_c3_histogram():
+    # ball-shaped cloud: pairs per z-slice of the 32^3 benchmark grid (rounded), 2/4/8 ranks
+    import math
+    w = [max(0.0, 1.0 - ((z - 15.5) / 13.5) ** 2) * 25000 for z in range(32)]
+    for world in (2, 4, 8):
+        b = PAR.slab_bounds(32, world, w)
+        _check_partition(b, 32, world)
+        loads = [sum(w[z0:z1]) for z0, z1 in b]
+        assert max(loads) <= 1.35 * sum(w) / world, (world, b, loads)

@@ -16,6 +16,12 @@ VP_ERR_UNSUPPORTED = -6
 VP_RM_QUANTIZE_UNORM8 = 1
 VP_RM_SHOW_NUM_SAMPLES = 2
 VP_RM_SHOW_BLEND_FUNC = 4
+VP_RM_SHOW_DRAW_ORDER = 8
+
+VP_CUBEMAP_F32 = 0
+VP_CUBEMAP_R8 = 1
+
+VPFX_ABI_VERSION = 2
 
 STATUS_NAMES = {
     0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
@@ -23,6 +29,25 @@ STATUS_NAMES = {
 }
 
 c_float_p = C.POINTER(C.c_float)
+
+
+def set_cubemap(params, array):
+    """Point vp_fill_params.cubemap at a numpy cube map [6, S, S]: float32 -> VP_CUBEMAP_F32, uint8 -> VP_CUBEMAP_R8.
+    `array` must be C-contiguous and stay alive for the call (None clears the pointer: keep the resident map)."""
+    if array is None:
+        params.cubemap = None
+        return
+    import numpy as np
+    if array.dtype == np.uint8:
+        params.cubemap_format = VP_CUBEMAP_R8
+    elif array.dtype == np.float32:
+        params.cubemap_format = VP_CUBEMAP_F32
+    else:
+        raise TypeError(f"cube map dtype {array.dtype}: float32 or uint8")
+    if not array.flags.c_contiguous or array.ndim != 3 or array.shape[0] != 6 or array.shape[1] != array.shape[2]:
+        raise ValueError("cube map must be a C-contiguous [6, S, S] array")
+    params.cubemap_size = array.shape[1]
+    params.cubemap = array.ctypes.data
 
 
 class vp_config(C.Structure):
@@ -66,8 +91,8 @@ class vp_fill_params(C.Structure):
         ("light_far", C.c_float),
         ("light_cam_distance", C.c_float),
         ("cubemap_size", C.c_int32),
-        ("reserved", C.c_int32),
-        ("cubemap", c_float_p),
+        ("cubemap_format", C.c_int32),
+        ("cubemap", C.c_void_p),
         ("light_depth_map", c_float_p),
     ]
 
@@ -114,8 +139,8 @@ class vp_stats(C.Structure):
 # every symbol include/vpfx.h declares (checked by tests/test_abi.py against the built library)
 EXPORTED_SYMBOLS = [
     "vp_create", "vp_destroy", "vp_last_error", "vp_abi_version", "vp_set_stream", "vp_sync", "vp_pin_host_buffer", "vp_unpin_host_buffer",
-    "vp_set_frame", "vp_bin", "vp_upload_particles", "vp_bin_resident", "vp_fill",
-    "vp_raymarch", "vp_raymarch_device", "vp_composite_device",
+    "vp_set_frame", "vp_bin", "vp_upload_particles", "vp_bin_resident", "vp_fill", "vp_fill_begin", "vp_fill_metavoxel",
+    "vp_raymarch", "vp_raymarch_device", "vp_clear_particles_rt", "vp_render_metavoxel", "vp_read_particles_rt", "vp_composite_device",
     "vp_fill_local", "vp_fill_finish", "vp_raymarch_partial_device", "vp_blend_partials_device",
     "vp_blend_partials_range_device",
     "vp_z_boundary", "vp_z_histogram", "vp_set_occluders", "vp_render_light_depth", "vp_render_scene_depth",

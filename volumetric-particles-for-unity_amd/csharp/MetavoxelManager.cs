@@ -8,8 +8,10 @@
 //
 // What it replaces in the reference (nothing else of the component changes):
 //   BinParticlesToMetavoxels()   VPR.cs:397-457   -> vp_bin
-//   FillMetavoxels()/FillMetavoxel VPR.cs:495-609 -> vp_fill   (no per-MV ComputeBuffer / Blit any more)
-//   RenderMetavoxels()/RenderMetavoxel VPR.cs:637-794 -> vp_raymarch (no per-MV DrawMeshNow / ROP blend)
+//   FillMetavoxels()             VPR.cs:495-520   -> vp_fill   (no per-MV ComputeBuffer / Blit any more)
+//   FillMetavoxel(xx,yy,zz)      VPR.cs:559-609   -> vp_fill_metavoxel (after FillMetavoxelsBegin = vp_fill_begin)
+//   RenderMetavoxels()           VPR.cs:637-713   -> vp_raymarch (no per-MV DrawMeshNow / ROP blend)
+//   RenderMetavoxel(xx,yy,zz,i)  VPR.cs:766-794   -> vp_render_metavoxel (one metavoxel blended into the library's particlesRT)
 //   UpdateMetavoxelPositions()   VPR.cs:370-394   -> vp_set_frame
 using System;
 using System.Runtime.InteropServices;
@@ -55,7 +57,7 @@ namespace MetavoxelEngine
         {
             public float opacity_factor, displacement_scale; public int fade_out_particles;
             public float ambient_r, ambient_g, ambient_b, init_light_intensity, light_near, light_far, light_cam_distance;
-            public int cubemap_size, reserved;
+            public int cubemap_size, cubemap_format;   // VP_CUBEMAP_F32 = 0, VP_CUBEMAP_R8 = 1
             public IntPtr cubemap, light_depth_map;
         }
         [StructLayout(LayoutKind.Sequential)]
@@ -69,7 +71,7 @@ namespace MetavoxelEngine
         struct vp_raymarch_params
         {
             public int steps_per_mv, soft_distance; public IntPtr scene_depth;
-            public int flags;      // VP_RM_* bits (1 = UNORM8 render-target emulation, 2 / 4 = debug views)
+            public int flags;      // VP_RM_* bits (1 = UNORM8 render-target emulation, 2 / 4 / 8 = debug views; 8 = _ShowMetavoxelDrawOrder)
             [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public int[] reserved;
         }
 
@@ -80,14 +82,23 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_set_frame(IntPtr ctx, float[] lightToWorld, float[] gridCenter);
         [DllImport(LIB)] static extern int vp_bin(IntPtr ctx, IntPtr particles, int count, ref vp_particle_layout layout, float[] psysLocalToWorld);
         [DllImport(LIB)] static extern int vp_fill(IntPtr ctx, ref vp_fill_params p);
+        [DllImport(LIB)] static extern int vp_fill_begin(IntPtr ctx, ref vp_fill_params p);
+        [DllImport(LIB)] static extern int vp_fill_metavoxel(IntPtr ctx, int xx, int yy, int zz);
         [DllImport(LIB)] static extern int vp_raymarch(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, IntPtr rgbaOut);
+        [DllImport(LIB)] static extern int vp_clear_particles_rt(IntPtr ctx);
+        [DllImport(LIB)] static extern int vp_render_metavoxel(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, int xx, int yy, int zz,
+                                                               int blendOver, int orderIndex);
+        [DllImport(LIB)] static extern int vp_read_particles_rt(IntPtr ctx, IntPtr rgbaOut);
         [DllImport(LIB)] static extern int vp_pin_host_buffer(IntPtr ctx, IntPtr ptr, ulong bytes);
         [DllImport(LIB)] static extern int vp_unpin_host_buffer(IntPtr ctx, IntPtr ptr);
 
         IntPtr ctx = IntPtr.Zero;
         ParticleSystem.Particle[] parts;
-        float[] cubemapR;              // .x channel of the displacement cubemap, faces +X,-X,+Y,-Y,+Z,-Z, row 0 = top
+        byte[] cubemapR;               // .x channel of the displacement cubemap as R8 (the asset is ARGB32, 8 bits per channel:
+                                       // Assets/Textures/DisplacementTexture.cubemap:10-23), faces +X,-X,+Y,-Y,+Z,-Z, row 0 = top
         bool cubemapResident = false;
+        bool filledOnce = false;
+        bool bShowMetavoxelDrawOrder = false;                              // VPR.cs:98
         float[] rgba;                  // particlesRT as float RGBA (premultiplied), row 0 = bottom
         GCHandle rgbaHandle;           // pinned for the component's lifetime (vp_pin_host_buffer)
         Texture2D particlesTex;
@@ -101,10 +112,11 @@ namespace MetavoxelEngine
             return a;
         }
 
-        void Check(int rc, string what)
+        bool Check(int rc, string what)
         {
             // the reference logs and carries on (VPR.cs:352,790); so do we
             if (rc != 0) Debug.LogError(what + " failed (" + rc + "): " + Marshal.PtrToStringAnsi(vp_last_error(ctx)));
+            return rc == 0;
         }
 
         void Start()                                                       // VPR.cs:132-149
@@ -122,13 +134,13 @@ namespace MetavoxelEngine
             vp_pin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject(), (ulong)rgba.Length * 4);   // speed hint only: failure is harmless
             particlesTex = new Texture2D(Screen.width, Screen.height, TextureFormat.RGBAFloat, false);
             int S = displacementTexture.width;
-            cubemapR = new float[6 * S * S];
+            cubemapR = new byte[6 * S * S];
             CubemapFace[] faces = { CubemapFace.PositiveX, CubemapFace.NegativeX, CubemapFace.PositiveY,
                                     CubemapFace.NegativeY, CubemapFace.PositiveZ, CubemapFace.NegativeZ };
             for (int f = 0; f < 6; f++)
             {
                 Color[] px = displacementTexture.GetPixels(faces[f]);
-                for (int i = 0; i < S * S; i++) cubemapR[f * S * S + i] = px[i].r;
+                for (int i = 0; i < S * S; i++) cubemapR[f * S * S + i] = (byte)Mathf.RoundToInt(px[i].r * 255f);   // exact for an 8-bit texture
             }
             lightOrientation = dirLight.transform.rotation;
             wsGridCenter = gridCenter.transform.position;
@@ -145,7 +157,8 @@ namespace MetavoxelEngine
         void OnPostRender()                                                // VPR.cs:181-220
         {
             if (ctx == IntPtr.Zero) return;
-            if (Time.frameCount % updateInterval == 0)
+            // the very first call always bins + fills: ray-marching before any fill is VP_ERR_STATE
+            if (Time.frameCount % updateInterval == 0 || !filledOnce)
             {
                 if (dirLight.transform.rotation != lightOrientation || wsGridCenter != gridCenter.transform.position)
                 {
@@ -184,29 +197,80 @@ namespace MetavoxelEngine
             finally { h.Free(); }
         }
 
-        void FillMetavoxels()                                              // VPR.cs:495-609 (+ SetFillPassConstants :523-554)
+        vp_fill_params FillParams()                                        // SetFillPassConstants VPR.cs:523-554
         {
-            var p = new vp_fill_params {
+            return new vp_fill_params {
                 opacity_factor = opacityFactor, displacement_scale = fDisplacementScale, fade_out_particles = fadeOutParticles ? 1 : 0,
                 ambient_r = ambientColor.x, ambient_g = ambientColor.y, ambient_b = ambientColor.z, init_light_intensity = 1.0f,
                 light_near = 0.3f, light_far = 1000f, light_cam_distance = 200f, cubemap_size = displacementTexture.width,
+                cubemap_format = 1 /* VP_CUBEMAP_R8 */,
                 cubemap = IntPtr.Zero, light_depth_map = IntPtr.Zero /* no occluders; pass the light depth map here when rendered */ };
+        }
+
+        void FillMetavoxels()                                              // VPR.cs:495-520
+        {
+            var p = FillParams();
             GCHandle h = default(GCHandle);
             if (!cubemapResident) { h = GCHandle.Alloc(cubemapR, GCHandleType.Pinned); p.cubemap = h.AddrOfPinnedObject(); }
-            try { Check(vp_fill(ctx, ref p), "vp_fill"); cubemapResident = true; }
+            try
+            {
+                // the cube map only counts as resident after a fill that SUCCEEDED: a failed first fill must upload it again
+                if (Check(vp_fill(ctx, ref p), "vp_fill")) { cubemapResident = true; filledOnce = true; }
+            }
             finally { if (h.IsAllocated) h.Free(); }
         }
 
-        public void RenderMetavoxels()                                     // VPR.cs:637-794 (+ SetRaymarchPassConstants :716-763)
+        // The reference's per-metavoxel entry point (VPR.cs:559-609), for a host that drives the fill itself: FillMetavoxelsBegin()
+        // (= the head of FillMetavoxels: constants + clear of lightPropogationTex, VPR.cs:497-503), then FillMetavoxel for every
+        // occupied metavoxel in zz-major order.
+        public void FillMetavoxelsBegin()
+        {
+            var p = FillParams();
+            GCHandle h = default(GCHandle);
+            if (!cubemapResident) { h = GCHandle.Alloc(cubemapR, GCHandleType.Pinned); p.cubemap = h.AddrOfPinnedObject(); }
+            try { if (Check(vp_fill_begin(ctx, ref p), "vp_fill_begin")) cubemapResident = true; }
+            finally { if (h.IsAllocated) h.Free(); }
+        }
+
+        public void FillMetavoxel(int xx, int yy, int zz)                  // VPR.cs:559-609
+        {
+            if (Check(vp_fill_metavoxel(ctx, xx, yy, zz), "vp_fill_metavoxel")) filledOnce = true;
+        }
+
+        void CameraAndParams(out vp_camera cam, out vp_raymarch_params rp)  // SetRaymarchPassConstants VPR.cs:716-763
         {
             Camera c = Camera.main;
             Vector3 cp = c.transform.position;
-            var cam = new vp_camera {
+            cam = new vp_camera {
                 world_to_camera = ToArray(c.worldToCameraMatrix), camera_to_world = ToArray(c.cameraToWorldMatrix),
                 px = cp.x, py = cp.y, pz = cp.z, fov_y = Mathf.Deg2Rad * c.fieldOfView, near_clip = c.nearClipPlane, far_clip = c.farClipPlane };
-            var rp = new vp_raymarch_params { steps_per_mv = rayMarchSteps, soft_distance = softParticleStepDistance,
-                                              scene_depth = IntPtr.Zero, flags = 0, reserved = new int[3] };
+            rp = new vp_raymarch_params { steps_per_mv = rayMarchSteps, soft_distance = softParticleStepDistance,
+                                          scene_depth = IntPtr.Zero, flags = bShowMetavoxelDrawOrder ? 8 : 0, reserved = new int[3] };
+        }
+
+        public void RenderMetavoxels()                                     // VPR.cs:637-713
+        {
+            if (!filledOnce) return;                                       // nothing filled yet: nothing to march
+            vp_camera cam; vp_raymarch_params rp;
+            CameraAndParams(out cam, out rp);
             Check(vp_raymarch(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch");
+            particlesTex.SetPixelData(rgba, 0);
+            particlesTex.Apply(false);
+        }
+
+        // The reference's per-metavoxel entry point (VPR.cs:766-794): one metavoxel marched and blended into the library's
+        // particlesRT with the blend state of its phase (blendOver: VPR.cs:659-662, else :688-691).  ClearParticlesRT() first
+        // (OnPreRender, VPR.cs:171), ReadParticlesRT() after the last one.
+        public void ClearParticlesRT() { Check(vp_clear_particles_rt(ctx), "vp_clear_particles_rt"); }
+        public void RenderMetavoxel(int xx, int yy, int zz, int orderIndex, bool blendOver)
+        {
+            vp_camera cam; vp_raymarch_params rp;
+            CameraAndParams(out cam, out rp);
+            Check(vp_render_metavoxel(ctx, ref cam, ref rp, xx, yy, zz, blendOver ? 1 : 0, orderIndex), "vp_render_metavoxel");
+        }
+        public void ReadParticlesRT()
+        {
+            Check(vp_read_particles_rt(ctx, rgbaHandle.AddrOfPinnedObject()), "vp_read_particles_rt");
             particlesTex.SetPixelData(rgba, 0);
             particlesTex.Apply(false);
         }
@@ -218,5 +282,6 @@ namespace MetavoxelEngine
         public void SetSoftParticleStepDistance(float v) { softParticleStepDistance = (int)v; }
         public void SetUpdateInterval(float v) { updateInterval = Mathf.Max(1, (int)v); }
         public void SetFadeOutParticles(bool v) { fadeOutParticles = v; }
+        public void SetShowMetavoxelDrawOrder(bool show) { bShowMetavoxelDrawOrder = show; }   // VPR.cs:1096-1099
     }
 }

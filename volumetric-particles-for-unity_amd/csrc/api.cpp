@@ -72,26 +72,41 @@ int ensure_bricks(vp_ctx* c, bool need_scratch)
 // upload the fill pass inputs that live behind pointers (cubemap, light depth map) and build the uniforms
 int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
 {
+    // netDisplacement = D * raw + (1 - D) must stay >= 0 (Fill.shader:119-126; the ao max and the smoothstep edges rely on it):
+    // the reference's slider is [0, 1] (scene:8103-8111).  Out-of-range inputs are refused, not silently mis-shaded.
+    if (!(p->displacement_scale >= 0.f && p->displacement_scale <= 1.f))
+        return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: displacement_scale %g outside [0, 1]", (double)p->displacement_scale);
     if (p->cubemap) {
         const int S = p->cubemap_size;
         if (S < 1 || S > 1024) return vp_fail(c, VP_ERR_BAD_ARG, "cubemap_size %d out of range", S);
+        if (p->cubemap_format != VP_CUBEMAP_F32 && p->cubemap_format != VP_CUBEMAP_R8)
+            return vp_fail(c, VP_ERR_BAD_ARG, "cubemap_format %d (VP_CUBEMAP_F32 or VP_CUBEMAP_R8)", p->cubemap_format);
         if (S != c->cubeS) {
             if (c->d_cubequads) VP_HIP(hipFree(c->d_cubequads));
             c->d_cubequads = nullptr;
+            c->cubeS = 0;                                      // no table resident until the new one is allocated AND built
             VP_HIP(hipMalloc((void**)&c->d_cubequads, (size_t)6 * (S + 1) * (S + 2) * sizeof(float2) + 16));
-            c->cubeS = S;
         }
-        float* d_cube = nullptr;
-        const size_t bytes = (size_t)6 * S * S * sizeof(float);
-        VP_HIP(hipMalloc((void**)&d_cube, bytes));
-        hipError_t e = hipMemcpyAsync(d_cube, p->cubemap, bytes, hipMemcpyHostToDevice, c->stream);
+        const int keepS = c->cubeS;
+        c->cubeS = 0;                                          // the resident table is being overwritten: invalid until it is rebuilt
+        void* d_cube = nullptr;
+        const size_t bytes = (size_t)6 * S * S * (p->cubemap_format == VP_CUBEMAP_R8 ? 1 : sizeof(float));
+        VP_HIP(hipMalloc(&d_cube, bytes));
+        int bad = 0;
+        int* d_bad = c->d_onecol + 1;
+        hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int), c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_cube, p->cubemap, bytes, hipMemcpyHostToDevice, c->stream);
         int rc = VP_OK;
-        if (e == hipSuccess) rc = launch_build_cubequads(c, d_cube, S);
+        if (e == hipSuccess) rc = launch_build_cubequads(c, d_cube, p->cubemap_format, S, d_bad);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamSynchronize(c->stream);       // the caller's cubemap pointer is not retained
         (void)hipFree(d_cube);
+        (void)keepS;
         if (e != hipSuccess || e2 != hipSuccess) return vp_fail(c, VP_ERR_HIP, "cubemap upload failed");
         if (rc) return rc;
-    } else if (!c->d_cubequads) {
+        if (bad) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: displacement cubemap has texels outside [0, 1] (or NaN)");
+        c->cubeS = S;
+    } else if (!c->d_cubequads || c->cubeS == 0) {
         return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: no displacement cubemap given and none resident");
     }
     if (p->light_depth_map) {
@@ -123,6 +138,8 @@ int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp
     if (!cam || !rp) return vp_fail(c, VP_ERR_BAD_ARG, "null camera / params");
     if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_raymarch before vp_fill");
     if (rp->steps_per_mv < 1 || rp->soft_distance < 1) return vp_fail(c, VP_ERR_BAD_ARG, "steps_per_mv and soft_distance must be >= 1");
+    if ((rp->flags & VP_RM_SHOW_DRAW_ORDER) && (c->g.z0 != 0 || c->g.z1 != c->g.Nz))
+        return vp_fail(c, VP_ERR_UNSUPPORTED, "VP_RM_SHOW_DRAW_ORDER needs a whole-grid context (mvCount runs over every slab)");
     hl_build_rm_consts(c, cam, rp, k);
     hl_build_rank(c, cam, c->h_rank);
     VP_HIP(hipMemcpyAsync(c->d_rank, c->h_rank, (size_t)c->g.Nx * c->g.Ny * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -190,7 +207,7 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
     if ((rc = dev_alloc(c, &c->d_mvPos, c->n3 * 3)) || (rc = dev_alloc(c, &c->d_count, c->n3)) ||
         (rc = dev_alloc(c, &c->d_offsets, c->n3 + 1)) || (rc = dev_alloc(c, &c->d_cursor, c->n3)) ||
         (rc = dev_alloc(c, &c->d_brick_index, c->n3)) || (rc = dev_alloc(c, &c->d_occ_list, c->n3)) ||
-        (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_colweight, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
+        (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_onecol, 2)) || (rc = dev_alloc(c, &c->d_colweight, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
         (rc = dev_alloc(c, (int4**)&c->d_scan_totals, (c->n3 + 1023) / 1024 + 1)) ||
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
@@ -209,7 +226,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
-                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_colweight, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
+                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_onecol, c->d_colweight, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
                    c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
@@ -315,7 +332,7 @@ VP_EXPORT int vp_bin_resident(vp_ctx* c)
     int rc = ensure_device(c); if (rc) return rc;
     rc = launch_bin(c); if (rc) return rc;
     c->binned = true;
-    c->filled = c->local_done = false;
+    c->filled = c->local_done = c->fill_begun = false;
     return VP_OK;
 }
 
@@ -354,6 +371,90 @@ VP_EXPORT int vp_fill(vp_ctx* c, const vp_fill_params* p)
     if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, false))) return rc;
     rc = launch_fill(c, 0, nullptr, c->d_lightmap); if (rc) return rc;
     c->filled = true;
+    return VP_OK;
+}
+
+// ---- the reference's per-metavoxel entry points ----------------------------------------------------------------------------
+VP_EXPORT int vp_fill_begin(vp_ctx* c, const vp_fill_params* p)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!p) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill_begin: null params");
+    int rc = check_fill_ready(c, "vp_fill_begin"); if (rc) return rc;
+    const size_t cap0 = c->brick_cap;
+    if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, false))) return rc;
+    // a freshly (re)allocated pool holds no textures yet: RenderTexture contents start out cleared
+    if (c->brick_cap != cap0) VP_HIP(hipMemsetAsync(c->d_bricks, 0, c->brick_cap * nv3(c) * sizeof(uint2), c->stream));
+    // GL.Clear(false, true, Color.red) on lightPropogationTex: 1.0 in the R channel                       VPR.cs:498-499
+    rc = launch_fill_value(c, c->d_lightmap, lightmap_elems(c), 1.0f); if (rc) return rc;
+    c->fill_begun = true;
+    c->filled = false;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_fill_metavoxel(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!c->fill_begun || !c->binned) return vp_fail(c, VP_ERR_STATE, "vp_fill_metavoxel before vp_fill_begin");
+    const GridConsts& g = c->g;
+    if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
+    if (zz < g.z0 || zz >= g.z1) return vp_fail(c, VP_ERR_BAD_ARG, "metavoxel slice %d is outside the owned slab [%d,%d)", zz, g.z0, g.z1);
+    int rc = ensure_device(c); if (rc) return rc;
+    rc = launch_fill_one(c, xx, yy, zz); if (rc) return rc;      // empty MV: the kernel skips it (VPR.cs:511)
+    c->filled = true;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_clear_particles_rt(vp_ctx* c)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipMemsetAsync(c->d_image, 0, image_elems(c) * sizeof(float), c->stream));                     // VPR.cs:171-172
+    VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
+    return VP_OK;
+}
+
+VP_EXPORT int vp_render_metavoxel(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, int32_t xx, int32_t yy, int32_t zz,
+                                  int32_t blend_over, int32_t order_index)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!cam || !rp) return vp_fail(c, VP_ERR_BAD_ARG, "vp_render_metavoxel: null camera / params");
+    if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_render_metavoxel before vp_fill");
+    if (rp->steps_per_mv < 1 || rp->soft_distance < 1) return vp_fail(c, VP_ERR_BAD_ARG, "steps_per_mv and soft_distance must be >= 1");
+    const GridConsts& g = c->g;
+    if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
+    int rc = ensure_device(c); if (rc) return rc;
+    const size_t mi = ((size_t)zz * g.Ny + yy) * g.Nx + xx;
+    int bi = -1;
+    VP_HIP(hipMemcpyAsync(&bi, c->d_brick_index + mi, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VP_HIP(hipStreamSynchronize(c->stream));
+    if (bi < 0) return VP_OK;                                    // empty / not owned: never submitted (VPR.cs:674, 703)
+    RmConsts k;
+    hl_build_rm_consts(c, cam, rp, &k);
+    float* keep = c->d_scene_depth;
+    if (rp->scene_depth) {
+        if (!c->d_scene_depth) { rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
+        keep = c->d_scene_depth;
+        VP_HIP(hipMemcpyAsync(c->d_scene_depth, rp->scene_depth, (size_t)c->cfg.width * c->cfg.height * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    } else if (c->n_occluders > 0) {
+        if (!c->d_scene_depth) { rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
+        keep = c->d_scene_depth;
+        rc = launch_scene_depth(c, cam, c->d_scene_depth); if (rc) return rc;
+    } else {
+        c->d_scene_depth = nullptr;
+    }
+    rc = launch_raymarch_one(c, k, bi, (int)mi, blend_over ? 1 : 0, order_index, c->d_image);
+    c->d_scene_depth = keep;
+    return rc;
+}
+
+VP_EXPORT int vp_read_particles_rt(vp_ctx* c, float* rgba_out)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_read_particles_rt: null output");
+    int rc = ensure_device(c); if (rc) return rc;
+    VP_HIP(hipMemcpyAsync(rgba_out, c->d_image, image_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    VP_HIP(hipStreamSynchronize(c->stream));
     return VP_OK;
 }
 

@@ -5,10 +5,11 @@
 // front-to-back propagate + RGBA16F store; draws serialised in z through a UAV (lightPropogationTex).
 //
 // CDNA4 shape (this file):
-//   * workgroup = 16x16 voxel columns (4 waves, each 16 px wide x 4 py: every slice store of a wave is four
-//     full 128-byte lines of the brick), persistent along the light axis: it walks its MV column zz = z0..z1
-//     carrying the transmitted light in a register, so the z-order dependency never leaves the chip and the
-//     light map is written once;
+//   * workgroup = 16x16 voxel columns (4 waves, each an 8x8-column tile: the most compact footprint against a
+//     particle's sphere, i.e. the highest lane utilisation in covered slices; a slice store of a wave is eight
+//     64-byte half lines), persistent along the light axis: it walks its MV column zz = z0..z1 carrying the
+//     transmitted light in a register, so the z-order dependency never leaves the chip and the light map is
+//     written once;
 //   * workgroups are dispatched heaviest-column-first (k_col_weight + k_col_rank) to bound the tail;
 //   * per (wave, particle): the column is a line ps(s) = A + s*B in particle space, so coverage is a quadratic
 //     in the slice index; each lane solves it, a DPP OR-reduction merges the per-lane slice masks, and only the
@@ -431,8 +432,15 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 // halves the table (0.8 MB at S = 128) and a 128-byte line spans 16 texels in x instead of 8, so neighbouring lanes and
 // slices share more lines: the per-voxel gather is bound by L2 requests (every lane pulls its own line), and this cut
 // k_fill from 5.57 to 5.09 ms at C3.
+// The source is the caller's cube map as uploaded: f32 texels, or R8 UNORM bytes (texel = byte / 255, the D3D11 UNORM -> float
+// conversion; the reference's asset is 8-bit).  A texel outside [0, 1] (or NaN) raises *bad: netDisplacement >= 0 is what
+// Fill.shader:119-126 and the ao max rely on, so vp_fill refuses such a map instead of silently diverging.
+__device__ __forceinline__ float cube_texel(const float* c, size_t i) { return c[i]; }
+__device__ __forceinline__ float cube_texel(const uint8_t* c, size_t i) { return (float)c[i] / 255.0f; }
+
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_build_cubequads(const float* __restrict__ cube, int S, float4* __restrict__ quads_)
+k_build_cubequads(const T* __restrict__ cube, int S, float4* __restrict__ quads_, int* __restrict__ bad)
 {
     float2* pairs = reinterpret_cast<float2*>(quads_);
     const int n = 6 * (S + 1) * (S + 2);
@@ -441,8 +449,17 @@ k_build_cubequads(const float* __restrict__ cube, int S, float4* __restrict__ qu
     const int ix = i % (S + 2) - 1, iy = (i / (S + 2)) % (S + 1) - 1, face = i / ((S + 2) * (S + 1));
     const int x0 = min(max(ix, 0), S - 1);
     const int y0 = min(max(iy, 0), S - 1), y1 = min(max(iy + 1, 0), S - 1);
-    const float* fc = cube + (size_t)face * S * S;
-    pairs[i] = make_float2(fc[y0 * S + x0], fc[y1 * S + x0]);
+    const size_t fo = (size_t)face * S * S;
+    const float a = cube_texel(cube, fo + y0 * S + x0), b = cube_texel(cube, fo + y1 * S + x0);
+    if (!(a >= 0.f && a <= 1.f) || !(b >= 0.f && b <= 1.f)) *bad = 1;
+    pairs[i] = make_float2(a, b);
+}
+
+__global__ void __launch_bounds__(256)
+k_fill_value(float* __restrict__ d, size_t n, float v)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d[i] = v;
 }
 
 template <int NV>
@@ -465,10 +482,54 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 
 }  // namespace
 
-int launch_build_cubequads(vp_ctx* c, const float* d_cube, int S)
+int launch_fill_value(vp_ctx* c, float* d, size_t n, float v)
+{
+    hipLaunchKernelGGL(k_fill_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, n, v);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int launch_build_cubequads(vp_ctx* c, const void* d_cube, int format, int S, int* d_bad)
 {
     const int n = 6 * (S + 1) * (S + 2);
-    hipLaunchKernelGGL(k_build_cubequads, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cube, S, c->d_cubequads);
+    if (format == VP_CUBEMAP_R8)
+        hipLaunchKernelGGL(k_build_cubequads<uint8_t>, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint8_t*)d_cube, S, c->d_cubequads, d_bad);
+    else
+        hipLaunchKernelGGL(k_build_cubequads<float>, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_cube, S, c->d_cubequads, d_bad);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+// FillMetavoxel(xx, yy, zz) (VPR.cs:559-609): the same kernel restricted to one metavoxel -- one MV column, zz in [zz, zz+1),
+// incoming light read from and transmitted light written back to the light-propagation map, exactly the UAV traffic of one
+// reference draw (Fill.shader:224, 250).
+int launch_fill_one(vp_ctx* c, int xx, int yy, int zz)
+{
+    const int col = yy * c->g.Nx + xx;
+    VP_HIP(hipMemcpyAsync(c->d_onecol, &col, sizeof(int), hipMemcpyHostToDevice, c->stream));   // pageable source: consumed on return
+    FillPtrs P{};
+    P.mvPos = c->d_mvPos; P.offsets = c->d_offsets; P.ids = c->d_ids; P.rec = c->d_rec;
+    P.brick_index = c->d_brick_index; P.colorder = c->d_onecol; P.cubequads = c->d_cubequads;
+    P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
+    P.light_in = c->d_lightmap; P.light_out = c->d_lightmap;
+    P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
+    GridConsts g = c->g;
+    g.z0 = zz; g.z1 = zz + 1;
+    const bool exact = c->cfg.exact_math == 1;
+    const dim3 block(256);
+#define VPFX_FILL_ONE(NV)                                                                                            \
+    do {                                                                                                              \
+        const dim3 grid((NV / 16) * (NV / 16));                                                                       \
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P));  \
+        else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P)); \
+    } while (0)
+    switch (c->g.nv) {
+    case 16: VPFX_FILL_ONE(16); break;
+    case 32: VPFX_FILL_ONE(32); break;
+    case 64: VPFX_FILL_ONE(64); break;
+    default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", c->g.nv);
+    }
+#undef VPFX_FILL_ONE
     VP_HIP(hipGetLastError());
     return VP_OK;
 }

@@ -155,6 +155,7 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
     k->zB = hl_z_boundary(c, cam);
     k->steps = rp->steps_per_mv; k->soft = rp->soft_distance;
     k->flags = rp->flags;
+    k->num_covered = c->h_meta.occupied;                                     // numMetavoxelsCovered  VPR.cs:515, 755
     k->aspect = (float)k->W / (float)k->H;                                   // RM.shader:190
     k->neg_inv_tan = -(1.0f / (float)std::tan((double)cam->fov_y * 0.5));    // RM.shader:193
     const float* w2c = cam->world_to_camera;

@@ -84,6 +84,50 @@ struct RayCtx {
     int tCameraG;             // camera lattice index estimated in grid space (traversal clamp only)
 };
 
+// Ray set-up of one pixel (RM.shader:188-224), once per ray: the camera-space ray, its image in grid space (traversal) and in
+// metavoxel space minus the per-MV translation (exactly the reference's per-draw arithmetic).
+__device__ __forceinline__ RayCtx ray_setup(const RmConsts& k, int col, int row, const float* __restrict__ scene_depth)
+{
+    float dx = (2.0f * ((float)col + 0.5f) / (float)k.W) - 1.0f;
+    const float dy = (2.0f * ((float)row + 0.5f) / (float)k.H) - 1.0f;
+    dx *= k.aspect;
+    const float dz = k.neg_inv_tan;
+    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float dirx = dx * inv, diry = dy * inv, dirz = dz * inv;
+    const float st = k.zMin / dirz;
+    const float sx = dirx * st, sy = diry * st, sz = dirz * st;                            // csAABBStart :212
+    RayCtx R;
+    R.ogx = ((k.c2g[0] * sx + k.c2g[1] * sy) + k.c2g[2] * sz) + k.c2g[3];
+    R.ogy = ((k.c2g[4] * sx + k.c2g[5] * sy) + k.c2g[6] * sz) + k.c2g[7];
+    R.ogz = ((k.c2g[8] * sx + k.c2g[9] * sy) + k.c2g[10] * sz) + k.c2g[11];
+    float gx = (k.c2g[0] * dirx + k.c2g[1] * diry) + k.c2g[2] * dirz;
+    float gy = (k.c2g[4] * dirx + k.c2g[5] * diry) + k.c2g[6] * dirz;
+    float gz = (k.c2g[8] * dirx + k.c2g[9] * diry) + k.c2g[10] * dirz;
+    const float ginv = 1.0f / sqrtf((gx * gx + gy * gy) + gz * gz);
+    R.dgx = gx * ginv; R.dgy = gy * ginv; R.dgz = gz * ginv;                               // mvRay.d :217
+    R.ivx = 1.0f / R.dgx; R.ivy = 1.0f / R.dgy; R.ivz = 1.0f / R.dgz;
+    R.startz = sz; R.dirz = dirz;
+    R.sceneDepth = scene_depth ? scene_depth[(size_t)row * k.W + col] : 3.0e38f;
+    {
+        const float cx = k.camg[0] - R.ogx, cy = k.camg[1] - R.ogy, cz = k.camg[2] - R.ogz;
+        R.tCameraG = (int)(sqrtf((cx * cx + cy * cy) + cz * cz) / k.mvStep);
+    }
+    // the ray in metavoxel space, minus the per-MV translation (exactly the reference's per-draw arithmetic)
+    R.lx = (k.c2m_lin[0] * sx + k.c2m_lin[1] * sy) + k.c2m_lin[2] * sz;
+    R.ly = (k.c2m_lin[3] * sx + k.c2m_lin[4] * sy) + k.c2m_lin[5] * sz;
+    R.lz = (k.c2m_lin[6] * sx + k.c2m_lin[7] * sy) + k.c2m_lin[8] * sz;
+    {
+        const float mx = (k.c2m_lin[0] * dirx + k.c2m_lin[1] * diry) + k.c2m_lin[2] * dirz;
+        const float my = (k.c2m_lin[3] * dirx + k.c2m_lin[4] * diry) + k.c2m_lin[5] * dirz;
+        const float mz = (k.c2m_lin[6] * dirx + k.c2m_lin[7] * diry) + k.c2m_lin[8] * dirz;
+        const float minv = 1.0f / sqrtf((mx * mx + my * my) + mz * mz);
+        R.dx = mx * minv; R.dy = my * minv; R.dz = mz * minv;
+        R.idx = 1.0f / R.dx; R.idy = 1.0f / R.dy; R.idz = 1.0f / R.dz;
+    }
+
+    return R;
+}
+
 // One metavoxel for one ray: RM.shader frag (166-302), arithmetic as the reference lays it out: the ray is
 // expressed in THIS metavoxel's unit-cube space through _CameraToMetavoxel (mv translation column `tr`), so
 // tEntry / tExit / tCamera are bit-identical to the per-draw values.  Returns false when the rasteriser would
@@ -211,6 +255,16 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
             : F4{1.0f, 0.f, 0.f, 0.5f};
     }
     return true;
+}
+
+// DrawOrderColoring (RM.shader:123-138): bright green -> dull green -> bright blue -> dull blue -> bright red -> dull red along
+// the submission order; integer arithmetic as in the shader.
+__device__ __forceinline__ F4 draw_order_color(int order_index, int num_covered)
+{
+    const int per = max((int)ceilf((float)num_covered / 3.0f), 1);      // numColorsPerChannel (>= 1: an MV is being drawn)
+    const int sel = order_index / per, idx = order_index % per;
+    const float v = (float)(per - idx) / (float)per;
+    return sel == 0 ? F4{0.f, v, 0.f, 1.f} : sel == 1 ? F4{0.f, 0.f, v, 1.f} : F4{v, 0.f, 0.f, 1.f};
 }
 
 // Translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld for every occupied MV
@@ -347,43 +401,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     const int row = tty * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (col >= k.W || row >= k.H) return;
 
-    // ray set-up                                                                          RM.shader:188-224
-    float dx = (2.0f * ((float)col + 0.5f) / (float)k.W) - 1.0f;
-    const float dy = (2.0f * ((float)row + 0.5f) / (float)k.H) - 1.0f;
-    dx *= k.aspect;
-    const float dz = k.neg_inv_tan;
-    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-    const float dirx = dx * inv, diry = dy * inv, dirz = dz * inv;
-    const float st = k.zMin / dirz;
-    const float sx = dirx * st, sy = diry * st, sz = dirz * st;                            // csAABBStart :212
-    RayCtx R;
-    R.ogx = ((k.c2g[0] * sx + k.c2g[1] * sy) + k.c2g[2] * sz) + k.c2g[3];
-    R.ogy = ((k.c2g[4] * sx + k.c2g[5] * sy) + k.c2g[6] * sz) + k.c2g[7];
-    R.ogz = ((k.c2g[8] * sx + k.c2g[9] * sy) + k.c2g[10] * sz) + k.c2g[11];
-    float gx = (k.c2g[0] * dirx + k.c2g[1] * diry) + k.c2g[2] * dirz;
-    float gy = (k.c2g[4] * dirx + k.c2g[5] * diry) + k.c2g[6] * dirz;
-    float gz = (k.c2g[8] * dirx + k.c2g[9] * diry) + k.c2g[10] * dirz;
-    const float ginv = 1.0f / sqrtf((gx * gx + gy * gy) + gz * gz);
-    R.dgx = gx * ginv; R.dgy = gy * ginv; R.dgz = gz * ginv;                               // mvRay.d :217
-    R.ivx = 1.0f / R.dgx; R.ivy = 1.0f / R.dgy; R.ivz = 1.0f / R.dgz;
-    R.startz = sz; R.dirz = dirz;
-    R.sceneDepth = scene_depth ? scene_depth[(size_t)row * k.W + col] : 3.0e38f;
-    {
-        const float cx = k.camg[0] - R.ogx, cy = k.camg[1] - R.ogy, cz = k.camg[2] - R.ogz;
-        R.tCameraG = (int)(sqrtf((cx * cx + cy * cy) + cz * cz) / k.mvStep);
-    }
-    // the ray in metavoxel space, minus the per-MV translation (exactly the reference's per-draw arithmetic)
-    R.lx = (k.c2m_lin[0] * sx + k.c2m_lin[1] * sy) + k.c2m_lin[2] * sz;
-    R.ly = (k.c2m_lin[3] * sx + k.c2m_lin[4] * sy) + k.c2m_lin[5] * sz;
-    R.lz = (k.c2m_lin[6] * sx + k.c2m_lin[7] * sy) + k.c2m_lin[8] * sz;
-    {
-        const float mx = (k.c2m_lin[0] * dirx + k.c2m_lin[1] * diry) + k.c2m_lin[2] * dirz;
-        const float my = (k.c2m_lin[3] * dirx + k.c2m_lin[4] * diry) + k.c2m_lin[5] * dirz;
-        const float mz = (k.c2m_lin[6] * dirx + k.c2m_lin[7] * diry) + k.c2m_lin[8] * dirz;
-        const float minv = 1.0f / sqrtf((mx * mx + my * my) + mz * mz);
-        R.dx = mx * minv; R.dy = my * minv; R.dz = mz * minv;
-        R.idx = 1.0f / R.dx; R.idy = 1.0f / R.dy; R.idz = 1.0f / R.dz;
-    }
+    const RayCtx R = ray_setup(k, col, row, scene_depth);
 
     F4 dstA{0.f, 0.f, 0.f, 0.f}, dstB{0.f, 0.f, 0.f, 0.f};                                 // OnPreRender clear  VPR.cs:171
     int nsamp = 0;
@@ -496,6 +514,8 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
                 src = phaseA ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
+            if (FLAGS && (k.flags & VP_RM_SHOW_DRAW_ORDER)) // debug view: position in the global submission order      RM.shader:170-173
+                src = draw_order_color(__float_as_int(mvtrans[bi].w), k.num_covered);
             if (over) {                         // Blend One OneMinusSrcAlpha                                  VPR.cs:659-662
                 const float ia = 1.0f - src.w;
                 d.x = src.x + d.x * ia; d.y = src.y + d.y * ia; d.z = src.z + d.z * ia; d.w = src.w + d.w * ia;
@@ -515,6 +535,60 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     const size_t pi = (size_t)row * k.W + col;
     img_over[pi] = make_float4(dstA.x, dstA.y, dstA.z, dstA.w);
     if (PARTIAL) img_under[pi] = make_float4(dstB.x, dstB.y, dstB.z, dstB.w);
+    if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
+}
+
+// _OrderIndex of every occupied metavoxel = its position in the submission order of RenderMetavoxels (mvCount, VPR.cs:650-706):
+// phase A (zz <= zBoundary) zz ascending, cells far -> near (rank descending); phase B zz ascending, cells near -> far.  Brick
+// slots are z-major, so the MVs of slice zz occupy consecutive slots and "occupied MVs in front of slice zz" = own slot minus the
+// occupied cells of the slice with a smaller cell index.  Only run for the VP_RM_SHOW_DRAW_ORDER view; stored in mvtrans[].w.
+__global__ void __launch_bounds__(256)
+k_order_index(RmConsts k, const int* __restrict__ occ_list, const int* __restrict__ brick_index, const int* __restrict__ rank, int n,
+              float4* __restrict__ mvtrans)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int nxy = k.Nx * k.Ny, mi = occ_list[i], zz = mi / nxy, cell = mi % nxy;
+    const int* occ = brick_index + zz * nxy;
+    const int r = rank[cell];
+    const bool phaseA = zz <= k.zB;
+    int before_in_slice = 0, lower_cells = 0;
+    for (int j = 0; j < nxy; ++j) {
+        if (occ[j] < 0) continue;
+        lower_cells += j < cell ? 1 : 0;
+        before_in_slice += (phaseA ? rank[j] > r : rank[j] < r) ? 1 : 0;
+    }
+    mvtrans[i].w = __int_as_float((i - lower_cells) + before_in_slice);
+}
+
+// RenderMetavoxel(xx, yy, zz, orderIndex) (VPR.cs:766-794) as the reference submits it: ONE metavoxel, every pixel of the target,
+// blended into particlesRT with the blend state RenderMetavoxels set (VPR.cs:659-662 OVER / 688-691 UNDER).  The per-metavoxel
+// entry point of the C ABI (debugging, literal replays of the reference's draw loop); the frame path is k_raymarch.
+template <int NV, bool WRAP>
+__global__ void __launch_bounds__(256)
+k_raymarch_one(RmConsts k, const uint2* __restrict__ brick, float4 tr, const float* __restrict__ scene_depth, float4* __restrict__ img,
+               int blend_over, int order_index, unsigned long long* __restrict__ samples)
+{
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), row = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (col >= k.W || row >= k.H) return;
+    const RayCtx R = ray_setup(k, col, row, scene_depth);
+    F4 src;
+    int nsamp = 0;
+    if (!march_mv<NV, WRAP, true>(k, R, brick, tr, src, nsamp)) return;       // no fragment: the ROP is not touched
+    if (k.flags & VP_RM_SHOW_BLEND_FUNC) src = blend_over ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
+    if (k.flags & VP_RM_SHOW_DRAW_ORDER) src = draw_order_color(order_index, k.num_covered);
+    const size_t pi = (size_t)row * k.W + col;
+    const float4 q = img[pi];
+    F4 d{q.x, q.y, q.z, q.w};
+    if (blend_over) {
+        const float ia = 1.0f - src.w;
+        d.x = src.x + d.x * ia; d.y = src.y + d.y * ia; d.z = src.z + d.z * ia; d.w = src.w + d.w * ia;
+    } else {
+        const float ia = 1.0f - d.w;
+        d.x = src.x * ia + d.x; d.y = src.y * ia + d.y; d.z = src.z * ia + d.z; d.w = src.w * ia + d.w;
+    }
+    if (k.flags & VP_RM_QUANTIZE_UNORM8) { d.x = unorm8(d.x); d.y = unorm8(d.y); d.z = unorm8(d.z); d.w = unorm8(d.w); }
+    img[pi] = make_float4(d.x, d.y, d.z, d.w);
     if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
 }
 
@@ -588,7 +662,7 @@ void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, i
 
 int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
 {
-    const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC))) ? 0 : 1;
+    const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) ? 0 : 1;
     VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
     const int nocc = c->h_meta.occupied;
     if ((size_t)nocc > c->mvtrans_cap) {
@@ -604,8 +678,12 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
         c->brick_hit_cap = (size_t)nocc + nocc / 8 + 16;
     }
     VP_HIP(hipMemsetAsync(c->d_brick_hit, 0, c->brick_hit_cap * sizeof(int), c->stream));
-    if (nocc > 0)
+    if (nocc > 0) {
         hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans);
+        if (k.flags & VP_RM_SHOW_DRAW_ORDER)
+            hipLaunchKernelGGL(k_order_index, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_brick_index, c->d_rank,
+                               nocc, c->d_mvtrans);
+    }
     VP_HIP(hipEventRecord(c->ev[2][0], c->stream));
     switch (k.nv) {
     case 16: launch_rm_nv<16>(c, k, d_over, d_under, early_out); break;
@@ -616,6 +694,39 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
     VP_HIP(hipGetLastError());
     VP_HIP(hipEventRecord(c->ev[2][1], c->stream));
     c->ev_valid[2] = true;
+    return VP_OK;
+}
+
+int launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_over, int order_index, float* d_img)
+{
+    // translation column of this metavoxel's _CameraToMetavoxel, same operation order as k_mv_trans (VPR.cs:774-778)
+    const float* mp = c->h_mvPos + 3 * (size_t)mi;
+    float tr[3];
+    for (int r = 0; r < 3; ++r) {
+        const float a = k.inv_rows[r * 3], b = k.inv_rows[r * 3 + 1], cc = k.inv_rows[r * 3 + 2];
+        const float t = -((a * mp[0] + b * mp[1]) + cc * mp[2]);
+        tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + cc * k.c2w_t[2]) + t * k.c2w_t[3];
+    }
+    const float4 trv = make_float4(tr[0], tr[1], tr[2], 0.f);
+    const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
+    const bool wrap = c->g.b < 1;
+    const size_t nv3 = (size_t)k.nv * k.nv * k.nv;
+    const uint2* brick = c->d_bricks + (size_t)bi * nv3;
+#define VPFX_RM_ONE(NV)                                                                                                        \
+    do {                                                                                                                        \
+        if (wrap) hipLaunchKernelGGL((k_raymarch_one<NV, true>), grid, block, 0, c->stream, k, brick, trv, c->d_scene_depth,    \
+                                     (float4*)d_img, blend_over, order_index, c->d_samples);                                    \
+        else      hipLaunchKernelGGL((k_raymarch_one<NV, false>), grid, block, 0, c->stream, k, brick, trv, c->d_scene_depth,   \
+                                     (float4*)d_img, blend_over, order_index, c->d_samples);                                    \
+    } while (0)
+    switch (k.nv) {
+    case 16: VPFX_RM_ONE(16); break;
+    case 32: VPFX_RM_ONE(32); break;
+    case 64: VPFX_RM_ONE(64); break;
+    default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", k.nv);
+    }
+#undef VPFX_RM_ONE
+    VP_HIP(hipGetLastError());
     return VP_OK;
 }
 

@@ -47,7 +47,7 @@ struct FillConsts {
 struct RmConsts {
     int W, H, Nx, Ny, Nz, nv, z0, z1;
     int zB, steps, soft, partial;
-    int flags, pad1, pad2, pad3;  // VP_RM_* bits of vp_raymarch_params.flags
+    int flags, num_covered, pad2, pad3;  // VP_RM_* bits of vp_raymarch_params.flags; _NumMetavoxelsCovered (VPR.cs:755)
     float aspect, neg_inv_tan, zMin, s;
     float mvStep, inv_mvStep, nearc, farc;
     float c2m_lin[9];             // linear part of _CameraToMetavoxel (identical for every MV), rows     VPR.cs:778
@@ -75,7 +75,7 @@ struct vp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     GridConsts g{};
-    bool have_frame = false, have_particles = false, binned = false, filled = false, local_done = false;
+    bool have_frame = false, have_particles = false, binned = false, filled = false, local_done = false, fill_begun = false;
 
     // frame
     float L[16]{}, gc[3]{};
@@ -102,6 +102,7 @@ struct vp_ctx {
     int* d_ids = nullptr;         // [pairs_cap]
     size_t pairs_cap = 0;
     int* d_colorder = nullptr;    // [Nx*Ny] MV columns, heaviest first
+    int* d_onecol = nullptr;      // [2] one MV column index (per-metavoxel fill) + the cube-map range flag
     int* d_colweight = nullptr;   // [Ny*Nx] pairs (+ a per-MV constant) per MV column: the sort key of d_colorder
     DevMeta* d_meta = nullptr;
     void* d_scan_totals = nullptr; // [ceil(N^3 / 1024)] per-tile totals of the two-launch scan
@@ -178,10 +179,13 @@ int  launch_extract(vp_ctx* c);
 int  launch_bin(vp_ctx* c);
 int  launch_z_histogram(vp_ctx* c, int* d_hist);
 // fill.hip
-int  launch_build_cubequads(vp_ctx* c, const float* d_cube, int S);
+int  launch_build_cubequads(vp_ctx* c, const void* d_cube, int format, int S, int* d_bad);
+int  launch_fill_one(vp_ctx* c, int xx, int yy, int zz);
+int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v);                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
 // raymarch.hip
 int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under);
+int  launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_over, int order_index, float* d_img);  // RenderMetavoxel VPR.cs:766
 int    launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out, size_t npix);
 int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);
 // occluders.hip

@@ -148,6 +148,14 @@ class Engine:
     def fill(self, params):
         self._ck(self.L.vp_fill(self.h, C.byref(params)), "vp_fill")
 
+    def fill_begin(self, params):
+        """Head of FillMetavoxels (VPR.cs:497-503): constants + light-propagation map cleared to 1."""
+        self._ck(self.L.vp_fill_begin(self.h, C.byref(params)), "vp_fill_begin")
+
+    def fill_metavoxel(self, xx, yy, zz):
+        """FillMetavoxel(xx, yy, zz) (VPR.cs:559)."""
+        self._ck(self.L.vp_fill_metavoxel(self.h, int(xx), int(yy), int(zz)), "vp_fill_metavoxel")
+
     def fill_local(self, params, d_tau_out: int):
         self._ck(self.L.vp_fill_local(self.h, C.byref(params), C.c_void_p(d_tau_out)), "vp_fill_local")
 
@@ -170,6 +178,19 @@ class Engine:
         if img.shape != (self.H, self.W, 4) or img.dtype != np.float32 or not img.flags.c_contiguous:
             raise ValueError("raymarch(out=...): float32 C-contiguous [H, W, 4] expected")
         self._ck(self.L.vp_raymarch(self.h, C.byref(cam), C.byref(rp), _vp(img)), "vp_raymarch")
+        return img
+
+    def clear_particles_rt(self):
+        self._ck(self.L.vp_clear_particles_rt(self.h), "vp_clear_particles_rt")
+
+    def render_metavoxel(self, cam, rp, xx, yy, zz, blend_over: bool, order_index: int = 0):
+        """RenderMetavoxel(xx, yy, zz, orderIndex) (VPR.cs:766) into the context's particlesRT."""
+        self._ck(self.L.vp_render_metavoxel(self.h, C.byref(cam), C.byref(rp), int(xx), int(yy), int(zz), 1 if blend_over else 0,
+                                            int(order_index)), "vp_render_metavoxel")
+
+    def read_particles_rt(self):
+        img = np.empty((self.H, self.W, 4), dtype=np.float32)
+        self._ck(self.L.vp_read_particles_rt(self.h, _vp(img)), "vp_read_particles_rt")
         return img
 
     def raymarch_device(self, cam, rp, d_rgba: int):

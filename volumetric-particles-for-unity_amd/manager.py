@@ -8,8 +8,11 @@ Same inspector field names (VPR.cs:72-101), same entry points and call order:
                                               every frame, composite over the scene
     UpdateMetavoxelPositions()   VPR.cs:370   vp_set_frame
     BinParticlesToMetavoxels()   VPR.cs:397   vp_bin
-    FillMetavoxels()             VPR.cs:495   vp_fill
-    RenderMetavoxels()           VPR.cs:637   vp_raymarch
+    FillMetavoxels()             VPR.cs:495   vp_fill               (one persistent launch)
+    FillMetavoxel(xx, yy, zz)    VPR.cs:559   vp_fill_metavoxel     (the reference's per-metavoxel draw, for debugging / replays)
+    RenderMetavoxels()           VPR.cs:637   vp_raymarch           (one launch)
+    RenderMetavoxel(xx,yy,zz,i)  VPR.cs:766   vp_render_metavoxel   (one metavoxel blended into particlesRT)
+    FillMetavoxelsPerDraw() / RenderMetavoxelsPerDraw(): the reference's literal loops over those two (VPR.cs:505-518, 652-711)
     Set*() GUI setters           VPR.cs:1040-1119
 
 This Python class exists because the container has no C# toolchain; `csharp/MetavoxelManager.cs` is the same
@@ -53,6 +56,8 @@ class MetavoxelManager:
         self._cubemap_dirty = True
         self.numMetavoxelsCovered = 0
         self.particlesRT = None
+        self._filled_once = False
+        self.showMetavoxelDrawOrder = False                                     # VPR.cs:754
 
     # ---- Unity callbacks ---------------------------------------------------------------------------------
     def Start(self):
@@ -65,7 +70,9 @@ class MetavoxelManager:
 
     def OnPostRender(self, frameCount, particles, layout, camera, mainSceneRT=None):
         """VPR.cs:181-220.  Returns particlesRT (and composites it over mainSceneRT in place when given)."""
-        if frameCount % self.updateInterval == 0:                               # :186
+        # the reference's first OnPostRender has frameCount % updateInterval == 0 (frame 0); a host that starts on another frame
+        # would ray-march textures that were never filled, so the first call always bins + fills
+        if frameCount % self.updateInterval == 0 or not self._filled_once:      # :186
             if self._frame_dirty:                                               # :188-195
                 self.UpdateMetavoxelPositions()
             self.BinParticlesToMetavoxels(particles, layout)                    # :197
@@ -87,7 +94,7 @@ class MetavoxelManager:
             self.UpdateMetavoxelPositions()
         self._engine.bin(particles, layout, self.psysLocalToWorld)
 
-    def FillMetavoxels(self):
+    def _fill_params(self):
         if self.displacementCubemap is None:
             raise ValueError("displacementCubemap is not set (FillVolume.mat binds _DisplacementTexture)")
         p = abi.vp_fill_params()
@@ -97,27 +104,96 @@ class MetavoxelManager:
         p.ambient[0], p.ambient[1], p.ambient[2] = self.ambientColor
         p.init_light_intensity = 1.0                                            # VPR.cs:540
         p.light_near, p.light_far, p.light_cam_distance = 0.3, 1000.0, 200.0    # VPR.cs:342,365
-        cube = np.ascontiguousarray(self.displacementCubemap, dtype=np.float32)
-        p.cubemap_size = cube.shape[1]
-        if self._cubemap_dirty:
-            p.cubemap = cube.ctypes.data_as(abi.c_float_p)                      # uploaded once, then resident
+        # float32 [6,S,S] in [0,1], or uint8 (R8: the reference's own asset is an 8-bit texture, DisplacementTexture.cubemap:10-23)
+        cube = np.ascontiguousarray(self.displacementCubemap)
+        if cube.dtype != np.uint8:
+            cube = np.ascontiguousarray(cube, dtype=np.float32)
+        abi.set_cubemap(p, cube)
+        if not self._cubemap_dirty:
+            p.cubemap = None                                                    # uploaded once, then resident
         depth = None
         if self.lightDepthMap is not None:
             depth = np.ascontiguousarray(self.lightDepthMap, dtype=np.float32)
             p.light_depth_map = depth.ctypes.data_as(abi.c_float_p)
+        return p, (cube, depth)                                                 # keep the arrays alive for the call
+
+    def FillMetavoxels(self):
+        p, keep = self._fill_params()
         self._engine.fill(p)
-        self._cubemap_dirty = False
+        self._cubemap_dirty = False                                             # only after a fill that succeeded (it raises otherwise)
+        self._filled_once = True
         self.numMetavoxelsCovered = self._engine.stats()["occupied_mv"]         # VPR.cs:515
 
-    def RenderMetavoxels(self, camera):
+    def FillMetavoxel(self, xx, yy, zz):
+        """VPR.cs:559-609: fill ONE metavoxel (light in/out through the light-propagation map).  Needs FillMetavoxelsBegin()."""
+        self._engine.fill_metavoxel(xx, yy, zz)
+
+    def FillMetavoxelsBegin(self):
+        """Head of FillMetavoxels (VPR.cs:497-503): SetFillPassConstants + clear of lightPropogationTex."""
+        p, keep = self._fill_params()
+        self._engine.fill_begin(p)
+        self._cubemap_dirty = False
+
+    def FillMetavoxelsPerDraw(self):
+        """The reference's literal loop: zz-major, then yy, then xx, one FillMetavoxel per occupied metavoxel (VPR.cs:505-518)."""
+        self.FillMetavoxelsBegin()
+        counts = self._engine.bin_counts()
+        self.numMetavoxelsCovered = 0
+        for zz in range(self.numMetavoxelsZ):
+            for yy in range(self.numMetavoxelsY):
+                for xx in range(self.numMetavoxelsX):
+                    if counts[zz, yy, xx] != 0:                                 # mParticlesCovered.Count != 0   :511
+                        self.FillMetavoxel(xx, yy, zz)
+                        self.numMetavoxelsCovered += 1
+        self._filled_once = True
+
+    def _raymarch_params(self):
         rp = abi.vp_raymarch_params()
         rp.steps_per_mv = self.rayMarchSteps
         rp.soft_distance = self.softParticleStepDistance
+        if self.showMetavoxelDrawOrder:
+            rp.flags |= abi.VP_RM_SHOW_DRAW_ORDER
         depth = None
         if self.sceneDepth is not None:
             depth = np.ascontiguousarray(self.sceneDepth, dtype=np.float32)
             rp.scene_depth = depth.ctypes.data_as(abi.c_float_p)
+        return rp, depth
+
+    def RenderMetavoxels(self, camera):
+        rp, keep = self._raymarch_params()
         return self._engine.raymarch(camera, rp)
+
+    def RenderMetavoxel(self, camera, xx, yy, zz, orderIndex=0, blendOver=False):
+        """VPR.cs:766-794: one metavoxel marched and blended into particlesRT with the blend state of its phase."""
+        rp, keep = self._raymarch_params()
+        self._engine.render_metavoxel(camera, rp, xx, yy, zz, blendOver, orderIndex)
+
+    def RenderMetavoxelsPerDraw(self, camera):
+        """The reference's literal submission loop (VPR.cs:637-713) over RenderMetavoxel; returns particlesRT."""
+        e = self._engine
+        counts = e.bin_counts()
+        pos = e.mv_positions()
+        cam_pos = np.array([camera.cam_pos[i] for i in range(3)], dtype=np.float32)
+        # SortMetavoxelSlicesFarToNearFromEye: keys from slice zz = 0, list built yy-major, stable ascending sort, reversed (VPR.cs:613-632)
+        d = pos[0].reshape(-1, 3) - cam_pos
+        key = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        near_to_far = np.argsort(key, kind="stable")
+        zb = e.z_boundary(camera)                                               # VPR.cs:642-648
+        e.clear_particles_rt()                                                  # OnPreRender                 VPR.cs:171
+        mvCount = 0
+        for zz in range(0, zb + 1):                                             # phase A: far -> near, OVER  VPR.cs:667-681
+            for c in near_to_far[::-1]:
+                xx, yy = int(c % self.numMetavoxelsX), int(c // self.numMetavoxelsX)
+                if counts[zz, yy, xx] != 0:
+                    self.RenderMetavoxel(camera, xx, yy, zz, mvCount, blendOver=True)
+                    mvCount += 1
+        for zz in range(zb + 1, self.numMetavoxelsZ):                           # phase B: near -> far, UNDER VPR.cs:695-711
+            for c in near_to_far:
+                xx, yy = int(c % self.numMetavoxelsX), int(c // self.numMetavoxelsX)
+                if counts[zz, yy, xx] != 0:
+                    self.RenderMetavoxel(camera, xx, yy, zz, mvCount, blendOver=False)
+                    mvCount += 1
+        return e.read_particles_rt()
 
     # ---- scene bindings ----------------------------------------------------------------------------------
     def SetLight(self, lightToWorld16):
@@ -144,6 +220,7 @@ class MetavoxelManager:
     def SetSoftParticleStepDistance(self, v): self.softParticleStepDistance = int(v)
     def SetUpdateInterval(self, v): self.updateInterval = max(1, int(v))
     def SetFadeOutParticles(self, v): self.fadeOutParticles = bool(v)
+    def SetShowMetavoxelDrawOrder(self, v): self.showMetavoxelDrawOrder = bool(v)   # VPR.cs:1096-1099 -> _ShowMetavoxelDrawOrder (:750-754)
     def SetAmbientColor(self, rgb): self.ambientColor = tuple(float(x) for x in rgb)
 
     @staticmethod

@@ -35,23 +35,26 @@ def slab_bounds(nz: int, world: int, weights: Sequence[float] | None = None) -> 
     if weights is None:
         cuts = [round(i * nz / world) for i in range(world + 1)]
     else:
-        w = [max(float(x), 0.0) + 1e-9 for x in weights]
+        if len(weights) != nz:
+            raise ValueError(f"{len(weights)} weights for {nz} z-slices")
+        w = [max(float(x), 0.0) for x in weights]
         total = sum(w)
-        cuts, acc, nxt = [0], 0.0, 1
-        for z in range(nz):
-            acc += w[z]
-            while nxt < world and acc >= total * nxt / world and z + 1 > cuts[-1]:
-                cuts.append(z + 1)
-                nxt += 1
-        while len(cuts) < world:
-            cuts.append(cuts[-1] + 1)
+        if not total > 0.0:
+            return slab_bounds(nz, world, None)
+        # ideal cut i = first z whose prefix sum reaches i/world of the work ...
+        cuts, acc, z = [0], 0.0, 0
+        for i in range(1, world):
+            target = total * i / world
+            while z < nz and acc + w[z] <= target:
+                acc += w[z]
+                z += 1
+            # cut after the slice that crosses the target if most of it lies in front of the target
+            cuts.append(z + 1 if (z < nz and (target - acc) > 0.5 * w[z]) else z)
         cuts.append(nz)
-        # repair: strictly increasing, last = nz
-        for i in range(1, world + 1):
-            cuts[i] = max(cuts[i], cuts[i - 1] + 1)
-        for i in range(world, 0, -1):
-            cuts[i - 1] = min(cuts[i - 1], cuts[i] - 1)
-        cuts[0], cuts[world] = 0, nz
+        # ... then forced into [i, nz - (world - i)] and strictly increasing (every rank owns >= 1 slice), in ONE
+        # forward pass: the upper clamp leaves room for the ranks behind, so no later step can push a cut past nz.
+        for i in range(1, world):
+            cuts[i] = min(max(cuts[i], cuts[i - 1] + 1), nz - (world - i))
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 

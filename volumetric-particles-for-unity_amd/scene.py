@@ -153,8 +153,7 @@ class Scene:
         p.init_light_intensity = 1.0
         p.light_near, p.light_far = 0.3, 1000.0
         p.light_cam_distance = 200.0
-        p.cubemap_size = self.cubemap.shape[1]
-        p.cubemap = self.cubemap.ctypes.data_as(abi.c_float_p)
+        abi.set_cubemap(p, self.cubemap)              # float32 [6,S,S] or uint8 (R8, the reference's asset format)
         if self.light_depth_map is not None:
             p.light_depth_map = self.light_depth_map.ctypes.data_as(abi.c_float_p)
         return p
