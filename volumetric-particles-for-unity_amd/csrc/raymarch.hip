@@ -414,7 +414,16 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         const float bz0 = R.ivz * ((float)k.z0 - R.ogz), bz1 = R.ivz * ((float)k.z1 - R.ogz);
         tg0 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
         tg1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-        tg0 = fmaxf(tg0, ((float)R.tCameraG - 2.0f) * k.mvStep);                           // nothing is sampled behind the camera
+        if (FLAGS && (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) {
+            // The debug views colour every RASTERISED fragment (RM.shader:170-181 return before the box test; :283-299 also colours
+            // a fragment with zero samples), i.e. every metavoxel whose exit point lies in front of the camera -- including those
+            // the lattice clamp below never samples (all of them when the camera is outside the z-slab, quirk Q13: tCamera is an
+            // unsigned distance).  So the walk starts at the camera itself (signed parameter along the ray), not at tCamera.
+            const float tcs = ((k.camg[0] - R.ogx) * R.dgx + (k.camg[1] - R.ogy) * R.dgy) + (k.camg[2] - R.ogz) * R.dgz;
+            tg0 = fmaxf(tg0, tcs);
+        } else {
+            tg0 = fmaxf(tg0, ((float)R.tCameraG - 2.0f) * k.mvStep);                       // nothing is sampled behind the camera
+        }
     }
     const int nxy = k.Nx * k.Ny;
     bool done = !(tg0 <= tg1);
