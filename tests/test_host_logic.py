@@ -56,7 +56,7 @@ def test_weighted_slabs_are_always_a_valid_partition():
     cuts past nz: nz=8, world=4, all the work in slice 6 gave [(0,7),(7,8),(8,9),(9,8)])."""
     import random
     rng = random.Random(99)
-    assert PAR.slab_bounds(8, 4, [0, 0, 0, 0, 0, 0, 19250, 0]) == [(0, 5), (5, 6), (6, 7), (7, 8)]
+    _check_partition(PAR.slab_bounds(8, 4, [0, 0, 0, 0, 0, 0, 19250, 0]), 8, 4)
     for nz in (1, 2, 3, 4, 8, 16, 32, 64):
         for world in sorted({1, 2, 3, 4, 8, nz // 2, nz - 1, nz}):
             if world < 1 or world > nz:
@@ -80,4 +80,21 @@ def test_weighted_slabs_do_not_lose_balance_on_the_c3_histogram():
         b = PAR.slab_bounds(32, world, w)
         _check_partition(b, 32, world)
         loads = [sum(w[z0:z1]) for z0, z1 in b]
-        assert max(loads) <= 1.35 * sum(w) / world, (world, b, loads)
+        assert max(loads) <= 1.2 * sum(w) / world, (world, b, loads)       # the DP cut is optimal: 1.0 / 1.06 / 1.16 here
+
+
+def test_weighted_slabs_minimise_the_heaviest_slab():
+    """Brute force over every contiguous partition on small cases: slab_bounds returns an optimum."""
+    import itertools, random
+    rng = random.Random(5)
+    for _ in range(60):
+        nz, world = rng.randint(2, 9), rng.randint(1, 4)
+        if world > nz:
+            continue
+        w = [rng.choice([0.0, rng.random(), 10 * rng.random()]) for _ in range(nz)]
+        if sum(w) == 0:
+            continue
+        best = min(max(sum(w[a:b]) for a, b in zip((0,) + c, c + (nz,))) for c in itertools.combinations(range(1, nz), world - 1))
+        b = PAR.slab_bounds(nz, world, w)
+        _check_partition(b, nz, world)
+        assert max(sum(w[z0:z1]) for z0, z1 in b) <= best * (1 + 1e-12) + 1e-12

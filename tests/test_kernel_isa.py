@@ -36,6 +36,7 @@ def test_fill_kernel_resources():
             continue
         seen += 1
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+        # the default-math kernels must keep 3 waves/SIMD (512 / 3 = 170 VGPRs); the EXACT (parity-test) variants may take more
         assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 168, name
     assert seen == 12
     asm = out.stdout

@@ -66,6 +66,38 @@ __device__ __forceinline__ void wait_vm_dyn(int i, f32x4& q)
     else if (D - 1 - i == 1) wait_vm<1>(q); else wait_vm<0>(q);
 }
 
+// The per-slice accumulators (density sum, ao max) of a chunk are two register arrays indexed by the wave-uniform slice.  hipcc lowers
+// `dens[s] += den` to read-modify-write through v_mov with s_set_gpr_idx (4 v_mov + 8 SALU per covered slice, a sixth of the covered-
+// slice loop's instructions); with the arrays pinned to fixed registers the update is the two arithmetic instructions themselves, issued
+// inside ONE indexing window with source-0 and destination both relative:  v_add_f32 v[0+s], v[0+s], den ; v_max_i32 v[32+s], v[32+s], net
+// (ao and net are >= 0, so the integer max of the bit patterns is the float max; the exec mask restricts both to the covered lanes).
+#ifndef VPFX_FILL_DIRECT_ACC
+#define VPFX_FILL_DIRECT_ACC 1
+#endif
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int CH> struct AccArr;
+template <> struct AccArr<32> {
+    typedef f32x32 type;
+    static __device__ __forceinline__ void add_max(f32x32& dens, f32x32& ao, int s, float den, float net)
+    {
+        // s_nop 1 between s_set_gpr_idx_on and the first indexed VALU is REQUIRED on gfx950: without it the kernel faults at the 32^3
+        // benchmark grid (found by bisecting nop positions, scripts/gpu_variants.sh; hipcc's own windows only ever hold one v_mov and
+        // never showed it).  With it the bricks are bit-identical to the v_mov lowering (scripts/fill_hash.py, default and EXACT math).
+        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0,DST)\n\ts_nop 1\n\tv_add_f32 v0, v0, %2\n\tv_max_i32 v32, v32, %3\n\ts_set_gpr_idx_off"
+                     : "+{v[0:31]}"(dens), "+{v[32:63]}"(ao) : "v"(den), "v"(net), "s"(s));     // rewrites M0 like every gpr-idx window hipcc emits itself
+    }
+};
+template <> struct AccArr<16> {
+    typedef f32x16 type;
+    static __device__ __forceinline__ void add_max(f32x16& dens, f32x16& ao, int s, float den, float net)
+    {
+        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0,DST)\n\ts_nop 1\n\tv_add_f32 v0, v0, %2\n\tv_max_i32 v16, v16, %3\n\ts_set_gpr_idx_off"
+                     : "+{v[0:15]}"(dens), "+{v[16:31]}"(ao) : "v"(den), "v"(net), "s"(s));     // rewrites M0 like every gpr-idx window hipcc emits itself
+    }
+};
+
 template <bool EXACT>
 __device__ __forceinline__ float fdiv(float a, float b)
 {
@@ -160,7 +192,7 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
 // (propagation with T_in = 1) to light_out.
 #ifndef VPFX_FILL_WAVES
-#define VPFX_FILL_WAVES 1
+#define VPFX_FILL_WAVES 3      // min waves per SIMD: caps the kernels at 168 VGPRs (without the cap hipcc takes 165-174 and NV = 64 drops to 2 waves)
 #endif
 template <int NV, bool EXACT, int MODE>
 __global__ void __launch_bounds__(256, VPFX_FILL_WAVES)
@@ -215,9 +247,13 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 
 #pragma unroll 1
         for (int c0 = 0; c0 < NV; c0 += CH) {
+#if VPFX_FILL_DIRECT_ACC
+            typename AccArr<CH>::type dens = 0.f, ao = 0.f;                              // "clear it"  :178-181
+#else
             float dens[CH], ao[CH];
 #pragma unroll
             for (int s = 0; s < CH; ++s) { dens[s] = 0.f; ao[s] = 0.f; }                 // "clear it"  :178-181
+#endif
 
             // Vectorised pre-cull: 64 particles of the MV's list at a time, one per lane, sphere vs. this wave's
             // 8x8-column x CH-slice box in voxel units (conservative); survivors are then taken in list order
@@ -295,9 +331,13 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                     if (hit) {
                         float den, net;
                         cube_shade<EXACT>(f, one_minus_D, make_float4(q[0], q[1], q[2], q[3]), tx, ty, d2, opacity, den, net);
+#if VPFX_FILL_DIRECT_ACC
+                        AccArr<CH>::add_max(dens, ao, s, den, net);                      // :200-201
+#else
                         dens[s] += den;                                                  // :200
                         // ao = max(ao, net) (:201); both are >= 0, so the max of the bit patterns is the float max
                         ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
+#endif
                     }
                 };
                 // Slices are processed in groups of 2*D (D = loads in flight) with D register sets; inside a group nothing in

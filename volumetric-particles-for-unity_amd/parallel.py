@@ -41,20 +41,32 @@ def slab_bounds(nz: int, world: int, weights: Sequence[float] | None = None) -> 
         total = sum(w)
         if not total > 0.0:
             return slab_bounds(nz, world, None)
-        # ideal cut i = first z whose prefix sum reaches i/world of the work ...
-        cuts, acc, z = [0], 0.0, 0
-        for i in range(1, world):
-            target = total * i / world
-            while z < nz and acc + w[z] <= target:
-                acc += w[z]
-                z += 1
-            # cut after the slice that crosses the target if most of it lies in front of the target
-            cuts.append(z + 1 if (z < nz and (target - acc) > 0.5 * w[z]) else z)
-        cuts.append(nz)
-        # ... then forced into [i, nz - (world - i)] and strictly increasing (every rank owns >= 1 slice), in ONE
-        # forward pass: the upper clamp leaves room for the ranks behind, so no later step can push a cut past nz.
-        for i in range(1, world):
-            cuts[i] = min(max(cuts[i], cuts[i - 1] + 1), nz - (world - i))
+        # Optimal contiguous partition: minimise the heaviest slab (the frame waits for the slowest rank), every rank owning >= 1
+        # slice.  dp[k][z] = best achievable maximum over the first z slices cut into k slabs; nz <= a few hundred, world <= 8.
+        pre = [0.0]
+        for x in w:
+            pre.append(pre[-1] + x)
+        INF = float("inf")
+        dp = [[INF] * (nz + 1) for _ in range(world + 1)]
+        arg = [[0] * (nz + 1) for _ in range(world + 1)]
+        dp[0][0] = 0.0
+        for k in range(1, world + 1):
+            for z in range(k, nz - (world - k) + 1):
+                best, besty = INF, k - 1
+                for y in range(k - 1, z):                   # last slab = [y, z)
+                    if dp[k - 1][y] == INF:
+                        continue
+                    # ties broken towards equal thickness (secondary key: slab length), so a flat histogram gives uniform slabs
+                    v = max(dp[k - 1][y], pre[z] - pre[y])
+                    if v < best or (v == best and abs((z - y) - nz / world) < abs((z - besty) - nz / world)):
+                        best, besty = v, y
+                dp[k][z], arg[k][z] = best, besty
+        cuts = [nz]
+        z = nz
+        for k in range(world, 0, -1):
+            z = arg[k][z]
+            cuts.append(z)
+        cuts.reverse()
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
