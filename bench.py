@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="scene name from vpfx_amd.scene.CONFIGS (default: the metric's config)")
+    ap.add_argument("--cubemap", default="r8", choices=["r8", "f32"],
+                    help="displacement cube map texel format: r8 = 8-bit like the reference's asset (LDS-resident in k_fill), f32 = float texels")
+    ap.add_argument("--no-lds-cubemap", action="store_true", help="A/B: keep an R8 cube map on the global f32 footprint table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
@@ -91,7 +94,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    sc = S.make_scene(args.config)
+    sc = S.make_scene(args.config, cubemap=args.cubemap)
     weights, whole_occupied = None, None
     if world > 1:
         # every rank computes the same (particle, MV)-pair histogram along the light axis (balanced slabs) and the
@@ -131,7 +134,10 @@ def main():
             ref_units = (st1["voxels_filled"], st1["samples"])
             one.close()
             torch.cuda.empty_cache()
-    eng = E.Engine(sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0)))
+    cfg = sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0))
+    if args.no_lds_cubemap:
+        cfg.reserved[0] = 1            # VPFX_CFG_NO_LDS_CUBEMAP
+    eng = E.Engine(cfg)
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
     pipe = PAR.SlabPipeline(PAR.HipSlabEngine(eng, device), bounds, rank, world, exchange=args.exchange)
@@ -226,6 +232,8 @@ def main():
             "dtype": "f32 compute / f16 voxel storage", "data": "synthetic",
             "config": {"workload": f"{args.config}: {sc.N[0]}x{sc.N[1]}x{sc.N[2]} metavoxels x {nv}^3 voxels, "
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
+                       "cubemap": ("R8 (8-bit like the reference's asset; LDS-resident in k_fill)" if args.cubemap == "r8" and not args.no_lds_cubemap
+                                   else "R8 on the global f32 footprint table" if args.cubemap == "r8" else "f32 texels, global footprint table"),
                        "parallelism": f"zslab{world}" + (f" ({args.exchange} exchange)" if world > 1 else ""), "slabs": bounds if world > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),

@@ -98,6 +98,17 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
         if (e == hipSuccess) e = hipMemcpyAsync(d_cube, p->cubemap, bytes, hipMemcpyHostToDevice, c->stream);
         int rc = VP_OK;
         if (e == hipSuccess) rc = launch_build_cubequads(c, d_cube, p->cubemap_format, S, d_bad);
+        // R8 maps that fit LDS (6 (S+2)^2 bytes <= 160 KB, i.e. S <= 163) also get the padded byte table of the persistent LDS fill
+        c->cube_u8_S = 0;
+        if (e == hipSuccess && !rc && p->cubemap_format == VP_CUBEMAP_R8 && cube_u8_bytes(S) <= (size_t)160 * 1024) {
+            const size_t need = cube_u8_bytes(S);
+            if (need > c->cube_u8_cap) {
+                if (c->d_cube_u8) (void)hipFree(c->d_cube_u8);
+                c->d_cube_u8 = nullptr; c->cube_u8_cap = 0;
+                if (hipMalloc((void**)&c->d_cube_u8, need) == hipSuccess) c->cube_u8_cap = need; else (void)hipGetLastError();
+            }
+            if (c->d_cube_u8 && launch_build_cube_u8(c, d_cube, S) == VP_OK) c->cube_u8_S = S;     // failure here only loses the fast path
+        }
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamSynchronize(c->stream);       // the caller's cubemap pointer is not retained
         (void)hipFree(d_cube);
@@ -203,11 +214,12 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
     if (!c->h_mvPos || !c->h_rank) { c->err = "vp_create: host allocation failed"; return fail(VP_ERR_OOM); }
     hl_build_grid(c);
     if ((rc = ensure_device(c))) return fail(rc);
+    if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c->num_cus < 1) c->num_cus = 256;
     const size_t nxy = (size_t)cfg->num_mv[0] * cfg->num_mv[1];
     if ((rc = dev_alloc(c, &c->d_mvPos, c->n3 * 3)) || (rc = dev_alloc(c, &c->d_count, c->n3)) ||
         (rc = dev_alloc(c, &c->d_offsets, c->n3 + 1)) || (rc = dev_alloc(c, &c->d_cursor, c->n3)) ||
         (rc = dev_alloc(c, &c->d_brick_index, c->n3)) || (rc = dev_alloc(c, &c->d_occ_list, c->n3)) ||
-        (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_onecol, 2)) || (rc = dev_alloc(c, &c->d_colweight, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
+        (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_onecol, 2)) || (rc = dev_alloc(c, &c->d_work_counter, 1)) || (rc = dev_alloc(c, &c->d_colweight, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
         (rc = dev_alloc(c, (int4**)&c->d_scan_totals, (c->n3 + 1023) / 1024 + 1)) ||
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
@@ -226,7 +238,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
-                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_onecol, c->d_colweight, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
+                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_onecol, c->d_work_counter, c->d_cube_u8, c->d_colweight, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
                    c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);

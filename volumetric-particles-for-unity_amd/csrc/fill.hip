@@ -98,6 +98,21 @@ template <> struct AccArr<16> {
     }
 };
 
+// LDS-resident cube map (TAB != 0): the bilinear quad is four ds_read_u8 (zero-extended bytes) off one address.  LDS operations
+// return in order among themselves, so "lgkmcnt <= 4 * (slices issued behind)" means the oldest slice's four bytes have landed
+// (other lgkm traffic -- the compiler's scalar loads -- only adds to the counter, i.e. makes the wait stricter, never laxer).
+struct QuadU8 { unsigned a, b, c, d; };          // texels (x0,y0), (x0,y0+1), (x0+1,y0), (x0+1,y0+1)
+template <int N>
+__device__ __forceinline__ void wait_lgkm(QuadU8& q)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(q.a), "+v"(q.b), "+v"(q.c), "+v"(q.d) : "n"(N) : "memory");
+}
+template <int D>
+__device__ __forceinline__ void wait_lgkm_dyn(int i, QuadU8& q)
+{
+    if (D - 1 - i >= 3) wait_lgkm<12>(q); else if (D - 1 - i == 2) wait_lgkm<8>(q); else if (D - 1 - i == 1) wait_lgkm<4>(q); else wait_lgkm<0>(q);
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float fdiv(float a, float b)
 {
@@ -126,8 +141,8 @@ struct FillPtrs {
 // memory access (the cubemap footprint) can be in flight while the next slice is being addressed:
 //   stage 1: texCUBE addressing  -> footprint index + bilinear weights
 //   stage 2: bilinear + displacement + smoothstep -> (density contribution, net displacement)
-template <bool EXACT>
-__device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx, float psy, float psz, float& tx, float& ty)
+template <bool EXACT, int TAB>
+__device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx, float psy, float psz, float& tx, float& ty, float lds_bias)
 {
     // D3D cube-face selection with the CDNA cube-map VALU instructions (v_cubeid/sc/tc/ma_f32): face id, the two in-face
     // coordinates and 2x the signed major component in four instructions instead of ~25 compares and selects.  Ties
@@ -158,17 +173,20 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     // the clamp-addressing of the footprint table never needs a min/max here.  The BYTE offset of the column pair,
     // 8 ((face (S+1) + y0 + 1)(S+2) + x0 + 1), is formed in float as three FMAs (exact: small integers) + one conversion.
     const float S2f = Sf + 2.0f;
-    return (unsigned)fmaf(fid, 8.0f * ((Sf + 1.0f) * S2f), fmaf(y0, 8.0f * S2f, fmaf(x0, 8.0f, 8.0f * (S2f + 1.0f))));
+    if (TAB == 0) return (unsigned)fmaf(fid, 8.0f * ((Sf + 1.0f) * S2f), fmaf(y0, 8.0f * S2f, fmaf(x0, 8.0f, 8.0f * (S2f + 1.0f))));
+    // LDS table: bytes [face][S+2][S+2] with the clamp border replicated; byte address (face (S+2) + y0 + 1)(S+2) + x0 + 1 + base,
+    // lds_bias = S + 3 + base (exact in float: < 2^24)
+    return (unsigned)fmaf(fid, S2f * S2f, fmaf(y0, S2f, x0 + lds_bias));
 }
 
 template <bool EXACT>
 __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
                                            const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
-                                           float d2, float opw, float& den, float& net)
+                                           float d2, float opw, float& den, float& net, float Dk /* D, or D/255 for byte texels */)
 {
     const float a = fmaf(tx, q.z - q.x, q.x), b = fmaf(tx, q.w - q.y, q.y);
     const float raw = fmaf(ty, b - a, a);
-    net = fmaf(f.D, raw, one_minus_D);                                            // netDisplacement   :119
+    net = fmaf(Dk, raw, one_minus_D);                                             // netDisplacement   :119
     float t;
     if (EXACT) {
         const float d2q = 4.0f * d2;                                              // dot(2ps, 2ps)     :121
@@ -194,20 +212,18 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
 #ifndef VPFX_FILL_WAVES
 #define VPFX_FILL_WAVES 3      // min waves per SIMD: caps the kernels at 168 VGPRs (without the cap hipcc takes 165-174 and NV = 64 drops to 2 waves)
 #endif
-template <int NV, bool EXACT, int MODE>
-__global__ void __launch_bounds__(256, VPFX_FILL_WAVES)
-k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
+// One wave's share of the fill: an 8x8-column tile (this lane: column px, py) of metavoxel column (xx, yy), walked along the light
+// axis zz = z0 .. z1.  TAB = 0: cube-map footprints from the global f32 pair table (p_cubequads);  TAB = 1 / 2: R8 cube map
+// resident in LDS (1: S = 128, row pitch 130 as instruction immediates; 2: any S, pitch from FillConsts).
+template <int NV, bool EXACT, int MODE, int TAB>
+__device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts& f, FILL_PTR_PARAMS, const int xx, const int yy, const int px,
+                                          const int py, const int lane, const unsigned lds_base)
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
     constexpr int PIPE = VPFX_FILL_PIPE;             // footprint loads in flight per wave
-    constexpr int TW = NV / 16;                      // 16x16-column tiles per MV edge
-    constexpr int TPM = TW * TW;
-    const int col = p_colorder[blockIdx.x / TPM];
-    const int tile = blockIdx.x % TPM;
-    const int xx = col % g.Nx, yy = col / g.Nx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = (tile % TW) * 16 + (wave & 1) * 8 + (lane & 7);      // wave = 8x8 columns: most compact footprint,
-    const int py = (tile / TW) * 16 + (wave >> 1) * 8 + (lane >> 3);    // highest lane utilisation in covered slices
+    static_assert(TAB == 0 || !EXACT, "the LDS (R8) path is default-math only: EXACT keeps the oracle's f32 table arithmetic");
+    const float lds_bias = f.half_s + f.half_s + 3.0f + (float)lds_base;
+    const float Dk = TAB == 0 ? f.D : f.D_over_255;
     const int LW = g.Nx * NV;
     const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
 
@@ -318,19 +334,34 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 // with PIPE register sets, so that PIPE footprint loads are in flight while the oldest slice is shaded.  hipcc
                 // cannot express "wait for the oldest of N loads" here (it emits vmcnt(0) around exec-masked regions), so the
                 // load and its wait are inline asm: loads return in order, hence vmcnt(N-1) == "the oldest one has landed".
-                auto stage1 = [&](int s, float& tx, float& ty, float& d2, bool& hit, f32x4& q) {
+                using Q = typename std::conditional<TAB == 0, f32x4, QuadU8>::type;
+                auto stage1 = [&](int s, float& tx, float& ty, float& d2, bool& hit, Q& q) {
                     const float fs = (float)(c0 + s);
                     const float psx = fmaf(fs, Bx, Ax), psy = fmaf(fs, By, Ay), psz = fmaf(fs, Bz, Az);
                     d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
                     hit = d2 <= 0.25f;                                                   // Fill.shader:172,196
-                    const unsigned qi = cube_address<EXACT>(f, psx, psy, psz, tx, ty);
-                    const unsigned off = hit ? qi : 0u;                                  // byte offset into the footprint table
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
+                    const unsigned qi = cube_address<EXACT, TAB>(f, psx, psy, psz, tx, ty, lds_bias);
+                    if constexpr (TAB == 0) {
+                        const unsigned off = hit ? qi : 0u;                              // byte offset into the footprint table
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
+                    } else if constexpr (TAB == 1) {
+                        const unsigned off = hit ? qi : lds_base;                        // lanes without a covered voxel all read byte 0 (a broadcast)
+                        asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:130\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:131"
+                                     : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
+                    } else {
+                        const unsigned off = hit ? qi : lds_base;
+                        const unsigned off2 = off + (unsigned)f.lds_pitch;                // the row below
+                        asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %5\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %5 offset:1"
+                                     : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off), "v"(off2) : "memory");
+                    }
                 };
-                auto stage2 = [&](int s, float tx, float ty, float d2, bool hit, const f32x4& q) {
+                auto stage2 = [&](int s, float tx, float ty, float d2, bool hit, const Q& q) {
                     if (hit) {
                         float den, net;
-                        cube_shade<EXACT>(f, one_minus_D, make_float4(q[0], q[1], q[2], q[3]), tx, ty, d2, opacity, den, net);
+                        float4 qf;
+                        if constexpr (TAB == 0) qf = make_float4(q[0], q[1], q[2], q[3]);
+                        else qf = make_float4((float)q.a, (float)q.b, (float)q.c, (float)q.d);   // bytes 0..255; 1/255 is folded into Dk
+                        cube_shade<EXACT>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk);
 #if VPFX_FILL_DIRECT_ACC
                         AccArr<CH>::add_max(dens, ao, s, den, net);                      // :200-201
 #else
@@ -347,18 +378,18 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 auto group = [&](auto depth) {
                     constexpr int D = decltype(depth)::value;
                     const int s = s_next;
-                    float tx[D], ty[D], d2[D]; bool hit[D]; f32x4 q[D];
+                    float tx[D], ty[D], d2[D]; bool hit[D]; Q q[D];
 #pragma unroll
                     for (int i = 0; i < D; ++i) stage1(s + i, tx[i], ty[i], d2[i], hit[i], q[i]);
 #pragma unroll
                     for (int i = 0; i < D; ++i) {
-                        wait_vm<D - 1>(q[i]);
+                        if constexpr (TAB == 0) wait_vm<D - 1>(q[i]); else wait_lgkm<4 * (D - 1)>(q[i]);
                         stage2(s + i, tx[i], ty[i], d2[i], hit[i], q[i]);
                         stage1(s + D + i, tx[i], ty[i], d2[i], hit[i], q[i]);
                     }
 #pragma unroll
                     for (int i = 0; i < D; ++i) {
-                        wait_vm_dyn<D>(i, q[i]);
+                        if constexpr (TAB == 0) wait_vm_dyn<D>(i, q[i]); else wait_lgkm_dyn<D>(i, q[i]);
                         stage2(s + D + i, tx[i], ty[i], d2[i], hit[i], q[i]);
                     }
                     s_next = s + 2 * D;
@@ -367,6 +398,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 // slices, so depths PIPE-1 .. 1 and one single slice cover it.  (Sequential ifs on purpose: an else-if chain
                 // or a loop over the depth made hipcc keep every depth's register sets alive at once.)
                 static_assert(PIPE >= 2 && PIPE <= 6, "remainder schedule written for PIPE = 2..6");
+                static_assert(TAB == 0 || PIPE <= 4, "lgkmcnt is a 4-bit counter: at most 4 slices (16 ds_read) in flight");
 #pragma unroll 1
                 while (s_next + 2 * PIPE - 1 <= s_last) group(std::integral_constant<int, PIPE>{});
                 if constexpr (PIPE >= 6) { if (s_next + 9 <= s_last) group(std::integral_constant<int, 5>{}); }
@@ -376,9 +408,9 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
                 if (s_next + 1 <= s_last) group(std::integral_constant<int, 1>{});
                 if (s_next <= s_last) {
                     const int s = s_next;
-                    float tx, ty, d2; bool hit; f32x4 q;
+                    float tx, ty, d2; bool hit; Q q;
                     stage1(s, tx, ty, d2, hit, q);
-                    wait_vm<0>(q);
+                    if constexpr (TAB == 0) wait_vm<0>(q); else wait_lgkm<0>(q);
                     stage2(s, tx, ty, d2, hit, q);
                 }
             }
@@ -405,6 +437,55 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
         }
     }
     p_light_out[lmi] = prop;                                                             // lightPropogationTex[..] :250
+}
+
+// Launch shape of the global-table path: workgroup = 16x16 voxel columns of one MV column (4 waves, each an 8x8 tile); MV columns
+// heaviest first.
+template <int NV, bool EXACT, int MODE>
+__global__ void __launch_bounds__(256, VPFX_FILL_WAVES)
+k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
+{
+    constexpr int TW = NV / 16;                      // 16x16-column tiles per MV edge
+    constexpr int TPM = TW * TW;
+    const int col = p_colorder[blockIdx.x / TPM];
+    const int tile = blockIdx.x % TPM;
+    const int xx = col % g.Nx, yy = col / g.Nx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = (tile % TW) * 16 + (wave & 1) * 8 + (lane & 7);      // wave = 8x8 columns: most compact footprint,
+    const int py = (tile / TW) * 16 + (wave >> 1) * 8 + (lane >> 3);    // highest lane utilisation in covered slices
+    fill_tile<NV, EXACT, MODE, 0>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
+                                  p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, 0u);
+}
+
+// R8 cube maps (the reference's own asset format): the whole map, 6 (S+2)^2 bytes with the clamp border replicated (99 KB at
+// S = 128), lives in LDS, so the per-voxel footprint gather never leaves the CU -- on the global table that gather, not the
+// arithmetic, is what k_fill waits for (one wave-wide divergent load per covered slice through the CU's single L1/TA path).
+// One PERSISTENT workgroup of 12 waves per CU (3 per SIMD, the same occupancy as k_fill) loads the table once; every wave then
+// pulls 8x8-column tiles from a global work counter, heaviest MV column first (finer-grained than k_fill's 4-wave workgroups: a wave
+// that finishes early starts the next tile instead of idling until its three siblings are done).
+template <int NV, int MODE, int TAB>
+__global__ void __launch_bounds__(768)
+k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
+           int nitems)
+{
+    extern __shared__ uint32_t lds_cube[];
+    for (int i = threadIdx.x; i < table_dwords; i += 768) lds_cube[i] = p_cube_u8[i];
+    __syncthreads();
+    const unsigned lds_base = (unsigned)(size_t)lds_cube;       // low half of the flat address of an LDS object = its LDS byte offset
+    constexpr int T8 = NV / 8, TPC = T8 * T8;                    // 8x8-column tiles per MV column
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(p_counter, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
+        const int col = p_colorder[item / TPC];
+        const int sub = item % TPC;
+        const int xx = col % g.Nx, yy = col / g.Nx;
+        const int px = (sub % T8) * 8 + (lane & 7), py = (sub / T8) * 8 + (lane >> 3);
+        fill_tile<NV, false, MODE, TAB>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
+                                        p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base);
+    }
 }
 
 // Second half of the split (multi-GPU) fill: stream density/ao back, propagate with the true incoming light.
@@ -502,6 +583,54 @@ k_fill_value(float* __restrict__ d, size_t n, float v)
     if (i < n) d[i] = v;
 }
 
+// LDS image of an R8 cube map: bytes [face][S+2][S+2], texel (ix, iy) for ix, iy in [-1, S] with clamp addressing baked in, so the
+// kernel's quad (ix, iy) .. (ix+1, iy+1), ix, iy in [-1, S-1], is four unguarded byte reads.
+__global__ void __launch_bounds__(256)
+k_build_cube_u8(const uint8_t* __restrict__ cube, int S, uint8_t* __restrict__ out, int nbytes)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbytes) return;
+    const int S2 = S + 2, n = 6 * S2 * S2;
+    uint8_t v = 0;
+    if (i < n) {
+        const int ix = i % S2 - 1, iy = (i / S2) % S2 - 1, face = i / (S2 * S2);
+        v = cube[(size_t)face * S * S + min(max(iy, 0), S - 1) * S + min(max(ix, 0), S - 1)];
+    }
+    out[i] = v;
+}
+
+// dynamic LDS above 64 KB has to be granted per kernel once
+template <typename K>
+int allow_big_lds(vp_ctx* c, K kernel, size_t bytes)
+{
+    VP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return VP_OK;
+}
+
+template <int NV, int MODE, int TAB>
+int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
+{
+    const size_t bytes = cube_u8_bytes(c->cube_u8_S);
+    auto kernel = k_fill_lds<NV, MODE, TAB>;
+    static bool granted = false;                      // per instantiation (the attribute sticks to the function)
+    if (!granted) { int rc = allow_big_lds(c, kernel, 160 * 1024); if (rc) return rc; granted = true; }
+    constexpr int TPC = (NV / 8) * (NV / 8);
+    const int nitems = c->g.Nx * c->g.Ny * TPC;
+    VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
+    const int grid = nitems < 12 * c->num_cus ? (nitems + 11) / 12 : c->num_cus;      // one persistent workgroup per CU
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(768), bytes, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), (const uint32_t*)c->d_cube_u8,
+                       (int)(bytes / 4), c->d_work_counter, nitems);
+    return VP_OK;
+}
+
+template <int NV>
+int launch_fill_lds_nv(vp_ctx* c, int mode, const FillPtrs& P)
+{
+    const bool s128 = c->cube_u8_S == 128;
+    if (mode == 0) return s128 ? launch_fill_lds_variant<NV, 0, 1>(c, P) : launch_fill_lds_variant<NV, 0, 2>(c, P);
+    return s128 ? launch_fill_lds_variant<NV, 1, 1>(c, P) : launch_fill_lds_variant<NV, 1, 2>(c, P);
+}
+
 template <int NV>
 int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 {
@@ -525,6 +654,16 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 int launch_fill_value(vp_ctx* c, float* d, size_t n, float v)
 {
     hipLaunchKernelGGL(k_fill_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, n, v);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+size_t cube_u8_bytes(int S) { return (((size_t)6 * (S + 2) * (S + 2)) + 15) & ~(size_t)15; }
+
+int launch_build_cube_u8(vp_ctx* c, const void* d_cube_r8, int S)
+{
+    const int nbytes = (int)cube_u8_bytes(S);
+    hipLaunchKernelGGL(k_build_cube_u8, dim3((nbytes + 255) / 256), dim3(256), 0, c->stream, (const uint8_t*)d_cube_r8, S, (uint8_t*)c->d_cube_u8, nbytes);
     VP_HIP(hipGetLastError());
     return VP_OK;
 }
@@ -583,14 +722,18 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     P.light_in = d_light_in; P.light_out = d_light_out;
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
     const bool exact = c->cfg.exact_math == 1;        // IEEE divisions everywhere (parity builds)
+    // R8 cube map resident as a byte table that fits LDS: the persistent LDS kernel (default math only; EXACT keeps the f32 table)
+    const bool lds = mode != 2 && !exact && c->cube_u8_S > 0 && c->cube_u8_S == c->cubeS && c->cfg.reserved[0] != VPFX_CFG_NO_LDS_CUBEMAP;
     const int evi = mode == 2 ? 3 : 1;
     VP_HIP(hipEventRecord(c->ev[evi][0], c->stream));
+    int rc = VP_OK;
     switch (c->g.nv) {
-    case 16: launch_fill_nv<16>(c, mode, P, exact); break;
-    case 32: launch_fill_nv<32>(c, mode, P, exact); break;
-    case 64: launch_fill_nv<64>(c, mode, P, exact); break;
+    case 16: rc = lds ? launch_fill_lds_nv<16>(c, mode, P) : launch_fill_nv<16>(c, mode, P, exact); break;
+    case 32: rc = lds ? launch_fill_lds_nv<32>(c, mode, P) : launch_fill_nv<32>(c, mode, P, exact); break;
+    case 64: rc = lds ? launch_fill_lds_nv<64>(c, mode, P) : launch_fill_nv<64>(c, mode, P, exact); break;
     default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", c->g.nv);
     }
+    if (rc) return rc;
     VP_HIP(hipGetLastError());
     VP_HIP(hipEventRecord(c->ev[evi][1], c->stream));
     c->ev_valid[evi] = true;

@@ -11,6 +11,9 @@
 
 #define VP_EXPORT extern "C" __attribute__((visibility("default")))
 
+// vp_config.reserved[0]: test / measurement switch -- 1 keeps an R8 cube map on the global f32 footprint table (A/B against the LDS path)
+#define VPFX_CFG_NO_LDS_CUBEMAP 1
+
 // ---------------------------------------------------------------------------------------------------
 // Kernel-constant PODs (passed by value as kernel arguments -> SGPRs / kernarg segment)
 // ---------------------------------------------------------------------------------------------------
@@ -42,6 +45,8 @@ struct FillConsts {
     int   cubeS;
     float half_s, half_s_m05;     // S/2, S/2 - 0.5
     int   border_index;           // nv - clamp(b, 0, nv-2)                                Fill.shader:229
+    float D_over_255;             // displacement scale for byte texels (R8 cube map in LDS): net = (D/255) * bilinear(bytes) + (1 - D)
+    int   lds_pitch;              // S + 2: row pitch of the padded byte table
 };
 
 struct RmConsts {
@@ -116,6 +121,11 @@ struct vp_ctx {
     float* d_lightmap = nullptr;  // [(Ny*nv)][(Nx*nv)]
     float4* d_cubequads = nullptr;// footprint table: float2 column pairs [6][S+1][S+2] (see k_build_cubequads)
     int cubeS = 0;
+    uint32_t* d_cube_u8 = nullptr;// R8 cube maps only: bytes [6][S+2][S+2], clamp border replicated (the LDS image of k_fill_lds)
+    size_t cube_u8_cap = 0;       // bytes allocated
+    int cube_u8_S = 0;            // 0 = no byte table resident (f32 cube map, or too large for LDS)
+    int* d_work_counter = nullptr;// tile counter of the persistent fill
+    int num_cus = 0;
     float* d_depthmap = nullptr;
     bool have_depthmap = false;
     FillConsts fc{};
@@ -180,6 +190,8 @@ int  launch_bin(vp_ctx* c);
 int  launch_z_histogram(vp_ctx* c, int* d_hist);
 // fill.hip
 int  launch_build_cubequads(vp_ctx* c, const void* d_cube, int format, int S, int* d_bad);
+int  launch_build_cube_u8(vp_ctx* c, const void* d_cube_r8, int S);                    // padded byte table for the LDS path
+size_t cube_u8_bytes(int S);                                                          // 6 (S+2)^2 rounded up to 16
 int  launch_fill_one(vp_ctx* c, int xx, int yy, int zz);
 int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v);                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish

@@ -85,6 +85,12 @@ def make_cubemap(size: int = 128, seed: int = 4321, lo: float = 0.1, hi: float =
     return np.ascontiguousarray((lo + (hi - lo) * full).astype(np.float32))
 
 
+def make_cubemap_r8(size: int = 128, seed: int = 4321, lo: float = 0.1, hi: float = 0.95) -> np.ndarray:
+    """The same smooth value noise as an 8-bit texture (uint8 [6,S,S], texel = byte/255): the format of the reference's own
+    displacement asset (ARGB32, Assets/Textures/DisplacementTexture.cubemap:10-23)."""
+    return np.ascontiguousarray(np.rint(make_cubemap(size, seed, lo, hi).astype(np.float64) * 255.0).astype(np.uint8))
+
+
 def look_at_camera(pos, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
     """Unity Transform.LookAt + Camera.cameraToWorldMatrix (view space looks down -Z)."""
     pos = np.asarray(pos, dtype=np.float64)
@@ -185,8 +191,9 @@ class Scene:
 
 
 def make_scene(name: str = "C1", *, seed: int = 1234, size_range=(0.6, 1.4), rotation_in_radians=False,
-               dims=None, border: int = 1, fade: int = 0) -> Scene:
-    """Build the section-8(d) scene for a named config (or dims=(N, nv, P, W, H))."""
+               dims=None, border: int = 1, fade: int = 0, cubemap: str = "f32") -> Scene:
+    """Build the section-8(d) scene for a named config (or dims=(N, nv, P, W, H)).  cubemap = "f32" (float texels) or "r8"
+    (the same noise as an 8-bit texture, the reference asset's format)."""
     N, nv, P, W, H = dims if dims is not None else CONFIGS[name]
     s = 3.0
     rng = np.random.default_rng(seed)
@@ -215,7 +222,7 @@ def make_scene(name: str = "C1", *, seed: int = 1234, size_range=(0.6, 1.4), rot
         psys_local_to_world=to_colmajor16(np.eye(4)),
         light_to_world=to_colmajor16(light),
         grid_center=np.zeros(3, dtype=np.float32),
-        cubemap=make_cubemap(), light_depth_map=None, scene_depth=None, fade=fade,
+        cubemap=make_cubemap_r8() if cubemap == "r8" else make_cubemap(), light_depth_map=None, scene_depth=None, fade=fade,
     )
     D = 0.8 * N * s
     sc.set_camera((-0.125 * D, 0.05 * D, -D))
