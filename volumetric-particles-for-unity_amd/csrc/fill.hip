@@ -26,6 +26,15 @@
 
 #include "vpfx_internal.h"
 
+#ifndef VPFX_FILL_PIPE_LDS
+#define VPFX_FILL_PIPE_LDS 2  // slices in flight on the LDS-resident cube map (4 ds_read_u8 each; lgkmcnt holds 15)
+#endif
+#ifndef VPFX_FILL_LDS_WAVES
+#define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
+#endif
+#ifndef VPFX_FILL_LDS_SELECT
+#define VPFX_FILL_LDS_SELECT 0   // 1: lanes without a covered voxel read byte 0 (costs a v_cndmask + hazard nops per slice; measured slower)
+#endif
 #ifndef VPFX_FILL_PIPE
 #define VPFX_FILL_PIPE 4      // 2..6; measured at C3: 2 -> 5.33 ms, 3 -> 5.07 (4 waves/SIMD), 4 -> 4.80 (3 waves/SIMD)
 #endif
@@ -80,6 +89,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int CH> struct AccArr;
 template <> struct AccArr<32> {
     typedef f32x32 type;
+    // "clear it" (Fill.shader:178-181) in place: `dens = 0.f` makes hipcc keep a 32-register zero tuple alive just to copy from
+    static __device__ __forceinline__ void clear(f32x32& dens, f32x32& ao)
+    {
+        asm volatile("v_mov_b32 v0, 0\n\tv_mov_b32 v1, 0\n\tv_mov_b32 v2, 0\n\tv_mov_b32 v3, 0\n\tv_mov_b32 v4, 0\n\tv_mov_b32 v5, 0\n\tv_mov_b32 v6, 0\n\tv_mov_b32 v7, 0\n\tv_mov_b32 v8, 0\n\tv_mov_b32 v9, 0\n\tv_mov_b32 v10, 0\n\tv_mov_b32 v11, 0\n\tv_mov_b32 v12, 0\n\tv_mov_b32 v13, 0\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0\n\tv_mov_b32 v16, 0\n\tv_mov_b32 v17, 0\n\tv_mov_b32 v18, 0\n\tv_mov_b32 v19, 0\n\tv_mov_b32 v20, 0\n\tv_mov_b32 v21, 0\n\tv_mov_b32 v22, 0\n\tv_mov_b32 v23, 0\n\tv_mov_b32 v24, 0\n\tv_mov_b32 v25, 0\n\tv_mov_b32 v26, 0\n\tv_mov_b32 v27, 0\n\tv_mov_b32 v28, 0\n\tv_mov_b32 v29, 0\n\tv_mov_b32 v30, 0\n\tv_mov_b32 v31, 0\n\tv_mov_b32 v32, 0\n\tv_mov_b32 v33, 0\n\tv_mov_b32 v34, 0\n\tv_mov_b32 v35, 0\n\tv_mov_b32 v36, 0\n\tv_mov_b32 v37, 0\n\tv_mov_b32 v38, 0\n\tv_mov_b32 v39, 0\n\tv_mov_b32 v40, 0\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v42, 0\n\tv_mov_b32 v43, 0\n\tv_mov_b32 v44, 0\n\tv_mov_b32 v45, 0\n\tv_mov_b32 v46, 0\n\tv_mov_b32 v47, 0\n\tv_mov_b32 v48, 0\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\tv_mov_b32 v52, 0\n\tv_mov_b32 v53, 0\n\tv_mov_b32 v54, 0\n\tv_mov_b32 v55, 0\n\tv_mov_b32 v56, 0\n\tv_mov_b32 v57, 0\n\tv_mov_b32 v58, 0\n\tv_mov_b32 v59, 0\n\tv_mov_b32 v60, 0\n\tv_mov_b32 v61, 0\n\tv_mov_b32 v62, 0\n\tv_mov_b32 v63, 0\n\t" : "={v[0:31]}"(dens), "={v[32:63]}"(ao));
+    }
     static __device__ __forceinline__ void add_max(f32x32& dens, f32x32& ao, int s, float den, float net)
     {
         // s_nop 1 between s_set_gpr_idx_on and the first indexed VALU is REQUIRED on gfx950: without it the kernel faults at the 32^3
@@ -91,6 +105,10 @@ template <> struct AccArr<32> {
 };
 template <> struct AccArr<16> {
     typedef f32x16 type;
+    static __device__ __forceinline__ void clear(f32x16& dens, f32x16& ao)
+    {
+        asm volatile("v_mov_b32 v0, 0\n\tv_mov_b32 v1, 0\n\tv_mov_b32 v2, 0\n\tv_mov_b32 v3, 0\n\tv_mov_b32 v4, 0\n\tv_mov_b32 v5, 0\n\tv_mov_b32 v6, 0\n\tv_mov_b32 v7, 0\n\tv_mov_b32 v8, 0\n\tv_mov_b32 v9, 0\n\tv_mov_b32 v10, 0\n\tv_mov_b32 v11, 0\n\tv_mov_b32 v12, 0\n\tv_mov_b32 v13, 0\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0\n\tv_mov_b32 v16, 0\n\tv_mov_b32 v17, 0\n\tv_mov_b32 v18, 0\n\tv_mov_b32 v19, 0\n\tv_mov_b32 v20, 0\n\tv_mov_b32 v21, 0\n\tv_mov_b32 v22, 0\n\tv_mov_b32 v23, 0\n\tv_mov_b32 v24, 0\n\tv_mov_b32 v25, 0\n\tv_mov_b32 v26, 0\n\tv_mov_b32 v27, 0\n\tv_mov_b32 v28, 0\n\tv_mov_b32 v29, 0\n\tv_mov_b32 v30, 0\n\tv_mov_b32 v31, 0\n\t" : "={v[0:15]}"(dens), "={v[16:31]}"(ao));
+    }
     static __device__ __forceinline__ void add_max(f32x16& dens, f32x16& ao, int s, float den, float net)
     {
         asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0,DST)\n\ts_nop 1\n\tv_add_f32 v0, v0, %2\n\tv_max_i32 v16, v16, %3\n\ts_set_gpr_idx_off"
@@ -161,7 +179,7 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     } else {
         // fast path: S / (2|major|) once (for the zero vector the clamp turns 1/0 into a finite number, sc = tc = 0 then
         // give the face centre like the EXACT branch), one FMA per axis
-        const float invS = Sf * fminf(__builtin_amdgcn_rcpf(ma2), 3.0e38f);
+        const float invS = Sf * fminf(__builtin_amdgcn_rcpf(ma2), 1.0e30f);   // (S * 1e30 stays finite: 0 * invS = 0, not NaN)
         fx = fmaf(sc, invS, f.half_s_m05); fy = fmaf(tc, invS, f.half_s_m05);
     }
     const float x0 = floorf(fx), y0 = floorf(fy);
@@ -220,7 +238,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                                           const int py, const int lane, const unsigned lds_base)
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
-    constexpr int PIPE = VPFX_FILL_PIPE;             // footprint loads in flight per wave
+    constexpr int PIPE = TAB == 0 ? VPFX_FILL_PIPE : VPFX_FILL_PIPE_LDS;   // footprint loads in flight per wave
     static_assert(TAB == 0 || !EXACT, "the LDS (R8) path is default-math only: EXACT keeps the oracle's f32 table arithmetic");
     const float lds_bias = f.half_s + f.half_s + 3.0f + (float)lds_base;
     const float Dk = TAB == 0 ? f.D : f.D_over_255;
@@ -264,7 +282,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 #pragma unroll 1
         for (int c0 = 0; c0 < NV; c0 += CH) {
 #if VPFX_FILL_DIRECT_ACC
-            typename AccArr<CH>::type dens = 0.f, ao = 0.f;                              // "clear it"  :178-181
+            typename AccArr<CH>::type dens, ao;
+            AccArr<CH>::clear(dens, ao);                                                 // "clear it"  :178-181
 #else
             float dens[CH], ao[CH];
 #pragma unroll
@@ -345,7 +364,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         const unsigned off = hit ? qi : 0u;                              // byte offset into the footprint table
                         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
                     } else if constexpr (TAB == 1) {
-                        const unsigned off = hit ? qi : lds_base;                        // lanes without a covered voxel all read byte 0 (a broadcast)
+                        const unsigned off = VPFX_FILL_LDS_SELECT ? (hit ? qi : lds_base) : qi;   // lanes without a covered voxel all read byte 0 (a broadcast)
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:130\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:131"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
                     } else {
@@ -464,12 +483,12 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 // pulls 8x8-column tiles from a global work counter, heaviest MV column first (finer-grained than k_fill's 4-wave workgroups: a wave
 // that finishes early starts the next tile instead of idling until its three siblings are done).
 template <int NV, int MODE, int TAB>
-__global__ void __launch_bounds__(768)
+__global__ void __launch_bounds__(64 * VPFX_FILL_LDS_WAVES)
 k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
            int nitems)
 {
     extern __shared__ uint32_t lds_cube[];
-    for (int i = threadIdx.x; i < table_dwords; i += 768) lds_cube[i] = p_cube_u8[i];
+    for (int i = threadIdx.x; i < table_dwords; i += 64 * VPFX_FILL_LDS_WAVES) lds_cube[i] = p_cube_u8[i];
     __syncthreads();
     const unsigned lds_base = (unsigned)(size_t)lds_cube;       // low half of the flat address of an LDS object = its LDS byte offset
     constexpr int T8 = NV / 8, TPC = T8 * T8;                    // 8x8-column tiles per MV column
@@ -617,8 +636,9 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     constexpr int TPC = (NV / 8) * (NV / 8);
     const int nitems = c->g.Nx * c->g.Ny * TPC;
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
-    const int grid = nitems < 12 * c->num_cus ? (nitems + 11) / 12 : c->num_cus;      // one persistent workgroup per CU
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(768), bytes, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), (const uint32_t*)c->d_cube_u8,
+    constexpr int WV = VPFX_FILL_LDS_WAVES;
+    const int grid = nitems < WV * c->num_cus ? (nitems + WV - 1) / WV : c->num_cus;   // one persistent workgroup per CU
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WV), bytes, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), (const uint32_t*)c->d_cube_u8,
                        (int)(bytes / 4), c->d_work_counter, nitems);
     return VP_OK;
 }
