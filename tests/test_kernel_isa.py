@@ -16,6 +16,13 @@ def test_pipelined_footprint_loads_are_never_touched_before_their_wait():
     assert m and int(m.group(1)) > 100, r.stdout
 
 
+def test_lds_cubemap_reads_are_never_touched_before_their_wait():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py"), "fill_lds"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"checked (\d+) k_fill_lds instantiations, (\d+) pipelined loads, 0 violations", r.stdout)
+    assert m and int(m.group(1)) == 12 and int(m.group(2)) >= 300, r.stdout
+
+
 def test_raymarch_texel_loads_are_never_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py"), "raymarch"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
