@@ -179,12 +179,14 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     } else {
         // fast path: S / (2|major|) once (for the zero vector the clamp turns 1/0 into a finite number, sc = tc = 0 then
         // give the face centre like the EXACT branch), one FMA per axis
-        const float invS = Sf * fminf(__builtin_amdgcn_rcpf(ma2), 1.0e30f);   // (S * 1e30 stays finite: 0 * invS = 0, not NaN)
+        const float invS = Sf * __builtin_amdgcn_rcpf(ma2 + 1.0e-30f);     // + 1e-30: bit-neutral for any real direction, keeps 1/0 finite
         fx = fmaf(sc, invS, f.half_s_m05); fy = fmaf(tc, invS, f.half_s_m05);
     }
     const float x0 = floorf(fx), y0 = floorf(fy);
     // EXACT keeps the oracle's fx - floor(fx); the fast path uses v_fract_f32 (identical except that a weight that
-    // would round up to exactly 1.0 is returned as the largest float below 1)
+    // would round up to exactly 1.0 is returned as the largest float below 1).  (Taking the index as fx - fract(fx), a full-rate
+    // subtract instead of the half-rate v_floor, and advancing the slice index with adds instead of converting it were measured:
+    // bit-identical bricks, no gain -- the kernel is not bound by those few VALU cycles.)
     tx = EXACT ? fx - x0 : __builtin_amdgcn_fractf(fx);
     ty = EXACT ? fy - y0 : __builtin_amdgcn_fractf(fy);
     // |sc|, |tc| <= |major|, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
