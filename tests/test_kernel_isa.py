@@ -52,3 +52,19 @@ def test_fill_kernel_resources():
     assert body.count("s_set_gpr_idx_on") >= 8
     assert body.count("v_cndmask") < 200            # a compare/select lowering of the 32-entry arrays would be thousands
     assert body.count("v_cubeid_f32") >= 4
+
+
+def test_raymarch_kernel_resources():
+    """Every k_raymarch / k_raymarch_one instantiation: no scratch (round 1 spilled 12 VGPRs at 96 VGPRs / 5 waves), 4 waves/SIMD."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                          "--cuda-device-only", "-S", SRC.replace("fill.hip", "raymarch.hip"), "-o", "/dev/null",
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
+    seen = 0
+    for b in re.split(r"Function Name: ", out.stderr)[1:]:
+        name = b.split()[0]
+        if "k_raymarch" not in name:
+            continue
+        seen += 1
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 128, name
+    assert seen == 30          # 24 k_raymarch + 6 k_raymarch_one

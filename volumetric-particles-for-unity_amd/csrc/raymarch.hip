@@ -41,6 +41,23 @@ struct __attribute__((aligned(8))) TexelPair { uint32_t rg0, ba0, rg1, ba1; };
 __device__ __forceinline__ float mix_lerp_lo(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(0) return d; }
 __device__ __forceinline__ float mix_lerp_hi(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(1) return d; }
 
+// d = w * t + acc with t fp16 (low or high half of a dword), w and acc f32, f32 arithmetic: one v_fma_mix_f32.  The trilinear filter as a
+// weighted sum of the eight texels costs 8 of these per channel (32 per sample, as many as the two-instruction x-lerps alone) + 15
+// full-rate VALU for the weights, against 32 + 8 sub + 8 fma + 10 packed for lerp-by-lerp: ~176 vs ~221 issue cycles per sample
+// (v_fma_mix_f32 / packed f32 issue at 4.3 cycles per wave, plain f32 mul / add / fma at 2.6 -- profiles/r02_valu_rate_probe.txt).
+#define VPFX_MIX_FMA(NAME, HI)                                                                                            \
+    __device__ __forceinline__ float NAME(float w, uint32_t t, float acc)                                                 \
+    {                                                                                                                     \
+        float d;                                                                                                          \
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0," #HI ",0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(t), "v"(acc));  \
+        return d;                                                                                                         \
+    }
+VPFX_MIX_FMA(mix_fma_lo, 0)
+VPFX_MIX_FMA(mix_fma_hi, 1)
+#ifndef VPFX_RM_WSUM
+#define VPFX_RM_WSUM 1
+#endif
+
 // Explicitly issued 16-byte loads for the two-samples-per-iteration loop: the compiler otherwise sinks the second
 // sample's loads below the first sample's filter (four loads in flight instead of eight).  The asynchronous register
 // write is invisible to the compiler, so wait_quad() takes the destinations as in/out operands: every use is ordered
@@ -203,8 +220,26 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math), then y
     // and z in f32.
     auto filter = [&](const Quad& q, const Addr& a) -> F4 {
+#if VPFX_RM_WSUM
+        // weighted sum of the eight texels (same value as the lerp cascade up to f32 rounding, ~1e-7)
+        const float ax = 1.0f - a.wx, ay = 1.0f - a.wy, az = 1.0f - a.wz;
+        const float w00 = ay * az, w10 = a.wy * az, w01 = ay * a.wz, w11 = a.wy * a.wz;         // [z][y]
+        const float w00a = w00 * ax, w00b = w00 * a.wx, w10a = w10 * ax, w10b = w10 * a.wx;
+        const float w01a = w01 * ax, w01b = w01 * a.wx, w11a = w11 * ax, w11b = w11 * a.wx;
+        F4 c;
+        c.x = mix_fma_lo(w11b, q.t11.rg1, mix_fma_lo(w11a, q.t11.rg0, mix_fma_lo(w01b, q.t01.rg1, mix_fma_lo(w01a, q.t01.rg0,
+              mix_fma_lo(w10b, q.t10.rg1, mix_fma_lo(w10a, q.t10.rg0, mix_fma_lo(w00b, q.t00.rg1, mix_fma_lo(w00a, q.t00.rg0, 0.f))))))));
+        c.y = mix_fma_hi(w11b, q.t11.rg1, mix_fma_hi(w11a, q.t11.rg0, mix_fma_hi(w01b, q.t01.rg1, mix_fma_hi(w01a, q.t01.rg0,
+              mix_fma_hi(w10b, q.t10.rg1, mix_fma_hi(w10a, q.t10.rg0, mix_fma_hi(w00b, q.t00.rg1, mix_fma_hi(w00a, q.t00.rg0, 0.f))))))));
+        c.z = mix_fma_lo(w11b, q.t11.ba1, mix_fma_lo(w11a, q.t11.ba0, mix_fma_lo(w01b, q.t01.ba1, mix_fma_lo(w01a, q.t01.ba0,
+              mix_fma_lo(w10b, q.t10.ba1, mix_fma_lo(w10a, q.t10.ba0, mix_fma_lo(w00b, q.t00.ba1, mix_fma_lo(w00a, q.t00.ba0, 0.f))))))));
+        c.w = mix_fma_hi(w11b, q.t11.ba1, mix_fma_hi(w11a, q.t11.ba0, mix_fma_hi(w01b, q.t01.ba1, mix_fma_hi(w01a, q.t01.ba0,
+              mix_fma_hi(w10b, q.t10.ba1, mix_fma_hi(w10a, q.t10.ba0, mix_fma_hi(w00b, q.t00.ba1, mix_fma_hi(w00a, q.t00.ba0, 0.f))))))));
+        return c;
+#else
         const F4 c00 = lerp_x(q.t00, a.wx), c10 = lerp_x(q.t10, a.wx), c01 = lerp_x(q.t01, a.wx), c11 = lerp_x(q.t11, a.wx);
         return lerp4(lerp4(c00, c10, a.wy), lerp4(c01, c11, a.wy), a.wz);
+#endif
     };
     auto blend = [&](const F4& c, float density) {
         const float bf = __builtin_amdgcn_rcpf(1.0f + density);                           // :272
@@ -371,7 +406,7 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 // FLAGS = false compiles the vp_raymarch_params.flags paths (UNORM8 emulation, debug views) out of the hot loop.
 // One wave per workgroup (no LDS, no barriers: a finished wave frees its slot at once), five waves per SIMD.
 #ifndef VPFX_RM_WAVES
-#define VPFX_RM_WAVES 5
+#define VPFX_RM_WAVES 4      // 115 VGPRs, no scratch (5 waves = 96 VGPRs spills 13 registers: measured 1.63 vs 1.58 ms at C3)
 #endif
 #ifndef VPFX_RM_WAVES_PARTIAL
 #define VPFX_RM_WAVES_PARTIAL VPFX_RM_WAVES
