@@ -33,6 +33,18 @@ from vpfx_amd import engine as E, parallel as PAR, scene as S  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def kernel_sources_sha():
+    """Fingerprint of the kernel sources: profiles/traffic_<cfg>.json records the one it was measured on, and bench.py only
+    reports that PMC measurement as `roofline.traffic` while it still matches (a stale number is worse than null)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(sc, threads=0):
     """Time the CPU oracle (a port of the reference's algorithm; the reference itself is C# + HLSL and cannot run
     here) on the GPU box's host cores.  Reported, not shipped: this is the only place bench.py touches oracle/."""
@@ -48,7 +60,7 @@ def cpu_baseline(sc, threads=0):
     t3 = time.perf_counter()
     st = o.stats()
     units = st["voxels_filled"] + st["samples"]
-    return {
+    out = {
         "value": units / (t3 - t0) / 1e6, "unit": "M(voxels+samples)/s", "cores": threads or O.Oracle.max_threads(),
         "kind": "port",
         "sample": f"one full step of {sc.name} (bin {t1 - t0:.3f}s, fill {t2 - t1:.3f}s, raymarch {t3 - t2:.3f}s)",
@@ -56,12 +68,36 @@ def cpu_baseline(sc, threads=0):
         "raymarch_msamples_per_s": st["samples"] / (t3 - t2) / 1e6,
         "seconds": t3 - t0,
     }
+    o.close()
+    # single-thread leg: ONE light-axis slice of the same workload (the middle one) on one thread, extrapolated
+    # to the whole step with the per-unit rates (a full single-thread step would take minutes)
+    zmid = sc.N[2] // 2
+    o1 = O.Oracle(sc.config(slab=(zmid, zmid + 1)), threads=1)
+    o1.set_frame(sc.light_to_world, sc.grid_center)
+    o1.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    s0 = time.perf_counter()
+    o1.fill(sc.fill_params())
+    s1 = time.perf_counter()
+    o1.raymarch_partial(sc.camera(), sc.raymarch_params())
+    s2 = time.perf_counter()
+    st1 = o1.stats()
+    fill_rate, rm_rate = st1["voxels_filled"] / (s1 - s0), st1["samples"] / max(s2 - s1, 1e-9)
+    est = st["voxels_filled"] / fill_rate + st["samples"] / rm_rate
+    out["single_thread"] = {
+        "cores": 1, "sample": f"light-axis slice zz = {zmid} of {sc.N[2]}: {st1['voxels_filled']} voxels in {s1 - s0:.2f}s, "
+                              f"{st1['samples']} samples in {s2 - s1:.2f}s",
+        "fill_mvoxels_per_s": fill_rate / 1e6, "raymarch_msamples_per_s": rm_rate / 1e6,
+        "seconds_1thread_full_step_extrapolated": est, "value": units / est / 1e6,
+        "parallel_speedup_of_the_port": est / (t3 - t0),
+    }
+    o1.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: >= 1 s of timed region at ~5 ms per step)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="scene name from vpfx_amd.scene.CONFIGS (default: the metric's config)")
     ap.add_argument("--cubemap", default="r8", choices=["r8", "f32"],
@@ -189,8 +225,9 @@ def main():
         # algorithmic bytes; rank-0 slab for N > 1
         fill_bytes = st["occupied_mv"] * (8 * nv ** 3 + 8 * nv ** 2) + 84 * st["pairs"]
         rm_bytes = st["bricks_sampled"] * 8 * nv ** 3 + 16 * sc.width * sc.height
+        lds_path = args.cubemap == "r8" and not args.no_lds_cubemap
         roofs = {
-            "fill": {"bound": "hbm", "kernel": "k_fill", "achieved": fill_bytes / (fill_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "fill": {"bound": "hbm", "kernel": "k_fill_lds" if lds_path else "k_fill", "achieved": fill_bytes / (fill_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "bytes_per_launch": fill_bytes, "avg_ms": fill_ms},
             "raymarch": {"bound": "hbm", "kernel": "k_raymarch", "achieved": rm_bytes / (rm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "bytes_per_launch": rm_bytes, "avg_ms": rm_ms,
@@ -198,21 +235,31 @@ def main():
         }
         # HBM traffic per launch measured with rocprofv3 PMC passes (scripts/gpu_prof2.sh -> profiles/*traffic*.json);
         # bench.py cannot collect PMC counters itself, so the committed measurement of this same command is reported.
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        traffic, tnote = {}, None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{args.cubemap}.json")
         if world == 1 and os.path.exists(tpath):
             traffic = json.load(open(tpath))
+            if traffic.get("kernel_sources_sha") != kernel_sources_sha() or args.no_lds_cubemap:
+                tnote = (f"profiles/{os.path.basename(tpath)} was measured on other kernel sources "
+                         f"({traffic.get('kernel_sources_sha')} != {kernel_sources_sha()}): not reported")
+                traffic = {}
         for name, r in roofs.items():
             r["frac"] = r["achieved"] / r["peak"]
             t = traffic.get(r["kernel"])
             r["traffic"] = t["traffic_bytes"] if t else None
             if t:
-                r["traffic_source"] = f"profiles/traffic_{args.config}.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                r["traffic_source"] = (f"profiles/{os.path.basename(tpath)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes of this "
+                                       f"command on these kernel sources, sha {traffic['kernel_sources_sha']})")
+            elif tnote:
+                r["traffic_note"] = tnote
         # what actually limits the two kernels (rocprofv3 PMC passes of this command, profiles/ + DESIGN.md 3.4): not HBM
-        roofs["fill"]["limiter"] = ("VALU issue (~80 % busy) + L2 request rate / L1 tag rate of the per-voxel cube-map gather "
-                                    "(~1.0 G TCP_TCC_READ_REQ, ~2.0 G TCP accesses per launch); HBM is at ~0.75 TB/s")
+        roofs["fill"]["limiter"] = (("VALU issue: ~2.0 G wave-level VALU per launch at ~4 cycles each = the whole kernel time (SQ_ACTIVE_INST_VALU x 4 / "
+                                     "SIMD-cycles ~ 1.0); the cube map is LDS-resident (LDS pipe ~60 % busy, 3/4 of it bank conflicts); HBM at ~0.9 TB/s")
+                                    if lds_path else
+                                    ("the CU's single L1/TA path: one divergent wave-wide footprint gather per covered slice (~65 cycles per "
+                                     "wave-slice per CU against ~38 of VALU); HBM at ~0.65 TB/s"))
         roofs["raymarch"]["limiter"] = ("VALU issue (~72 % busy) + L1/TA rate of the trilinear footprint loads "
-                                        "(4 x 16 B per sample per lane, 64 B/clk/CU); HBM is at ~1.9 TB/s")
+                                        "(4 x 16 B per sample per lane, 64 B/clk/CU); HBM is at ~2 TB/s")
         smax = [float(x) for x in stage_max.tolist()]
         # whole-job algorithmic bytes (all ranks): bricks + light map + pair records; bricks sampled + the image
         fill_bytes_job = occupied * (8 * nv ** 3 + 8 * nv ** 2) + 84 * pairs

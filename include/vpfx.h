@@ -245,6 +245,9 @@ int  vp_render_scene_depth(vp_ctx* ctx, const vp_camera* cam, float* out /* [H][
  *                     NULL = 1.0) and store the bricks. */
 int  vp_fill_local(vp_ctx* ctx, const vp_fill_params* params, void* d_tau_out);
 int  vp_fill_finish(vp_ctx* ctx, const void* d_light_in);
+/* The same with the product fused in: d_tau_all = the all-gathered transmittance maps [world][(Ny*nv)][(Nx*nv)] f32 (device),
+ * this context being slab `rank` of `world`; T_in = tau[0] * tau[1] * ... * tau[rank-1] (slab order) is formed inside the kernel. */
+int  vp_fill_finish_gathered(vp_ctx* ctx, const void* d_tau_all, int32_t rank, int32_t world);
 /* Partial images of the owned slab: d_over = composite of its MVs drawn in the OVER phase (zz <= zBoundary),
  * d_under = composite of those in the UNDER phase; each [H][W][4] f32 device.  *phase_mask gets bit0 if
  * the OVER image is non-empty, bit1 for UNDER. */

@@ -10,8 +10,16 @@ def mean(db, counter):
     rows = cur.fetchall(); con.close()
     return {n.replace("(anonymous namespace)::", "").replace("void ", "").split("<")[0].split("(")[0]: (v, k) for n, v, k in rows}
 f, w = mean(sys.argv[1], "FETCH_SIZE"), mean(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in ("k_fill", "k_raymarch"):
+import hashlib, os
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "volumetric-particles-for-unity_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            h.update(fn.encode() + b"\0" + open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+out = {"kernel_sources_sha": kernel_sources_sha()}
+for k in ("k_fill", "k_fill_lds", "k_raymarch"):
     if k in f and k in w:
         fk, wk = f[k][0] * 1024.0, w[k][0] * 1024.0
         out[k] = {"FETCH_SIZE_bytes_raw": fk, "WRITE_SIZE_bytes": wk, "launches_averaged": f[k][1],

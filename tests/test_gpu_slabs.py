@@ -12,7 +12,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def run_slabs(sc, world, cam_pos=None, weights=None, **engine_kw):
+def run_slabs(sc, world, cam_pos=None, weights=None, gathered=True, **engine_kw):
     dev = torch.device("cuda", 0)
     if cam_pos is not None:
         sc.set_camera(cam_pos)
@@ -28,11 +28,15 @@ def run_slabs(sc, world, cam_pos=None, weights=None, **engine_kw):
     for h in engs:
         h.bin_resident()
         taus.append(h.fill_local(sc.fill_params()).clone())
+    tau_all = torch.stack(taus).contiguous()           # what the all-gather delivers: [world, LH, LW]
     for r, h in enumerate(engs):
-        t_in = None
-        for j in range(r):
-            t_in = taus[j].clone() if t_in is None else t_in.mul_(taus[j])
-        h.fill_finish(t_in)
+        if gathered:                                   # product of the nearer slabs' maps formed inside the finish kernel
+            h.fill_finish_gathered(tau_all, r, world)
+        else:
+            t_in = None
+            for j in range(r):
+                t_in = taus[j].clone() if t_in is None else t_in.mul_(taus[j])
+            h.fill_finish(t_in)
     cam, rp = sc.camera(), sc.raymarch_params()
     zb = engs[0].z_boundary(cam)
     plan, straddler = PAR.blend_plan(bounds, zb)
@@ -170,3 +174,11 @@ def test_config4_c3_sharded_matches_single_engine_and_oracle(world, c3_reference
     for h in engs:
         h.e.close()
     torch.cuda.empty_cache()
+
+
+def test_fused_tau_product_is_bit_identical_to_the_explicit_product():
+    sc = S.make_scene("C1")
+    a = run_slabs(sc, 4, gathered=True)
+    b = run_slabs(S.make_scene("C1"), 4, gathered=False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])

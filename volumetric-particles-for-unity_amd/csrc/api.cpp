@@ -492,6 +492,21 @@ VP_EXPORT int vp_fill_finish(vp_ctx* c, const void* d_light_in)
     return VP_OK;
 }
 
+VP_EXPORT int vp_fill_finish_gathered(vp_ctx* c, const void* d_tau_all, int32_t rank, int32_t world)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!d_tau_all || world < 1 || rank < 0 || rank >= world) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill_finish_gathered: bad argument");
+    if (!c->local_done) return vp_fail(c, VP_ERR_STATE, "vp_fill_finish_gathered before vp_fill_local");
+    int rc = ensure_device(c); if (rc) return rc;
+    c->finish_tau_all = rank > 0 ? (const float*)d_tau_all : nullptr;      // rank 0: nothing nearer the light, T_in = 1
+    c->finish_n_before = rank;
+    rc = launch_fill(c, 2, nullptr, c->d_lightmap);
+    c->finish_tau_all = nullptr; c->finish_n_before = 0;
+    if (rc) return rc;
+    c->filled = true;
+    return VP_OK;
+}
+
 VP_EXPORT int vp_raymarch_device(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, void* d_rgba_out)
 {
     if (!c) return VP_ERR_BAD_ARG;

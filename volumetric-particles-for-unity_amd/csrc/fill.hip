@@ -512,7 +512,7 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
 // Second half of the split (multi-GPU) fill: stream density/ao back, propagate with the true incoming light.
 template <int NV>
 __global__ void __launch_bounds__(256)
-k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
+k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const float* __restrict__ p_tau_all /* nullable */, int n_before, size_t plane)
 {
     constexpr int TW = NV / 16;
     constexpr int TPM = TW * TW;
@@ -533,6 +533,11 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
     const float dm = p_depthmap ? p_depthmap[lmi] : 1.0f;
     const float lsSceneDepth = (dm - f.bq) * f.inv_a;
     float prop = p_light_in ? p_light_in[lmi] : 1.0f;
+    if (p_tau_all) {
+        // incoming light = product of the transmittance maps of the slabs nearer the light, in slab order (the gathered
+        // [world][LH][LW] buffer of the all-gather, straight from the collective: no intermediate product tensor)
+        for (int j = 0; j < n_before; ++j) prop = j == 0 ? p_tau_all[lmi] : prop * p_tau_all[(size_t)j * plane + lmi];
+    }
     for (int zz = g.z0; zz < g.z1; ++zz) {
         const int mi = (zz * g.Ny + yy) * g.Nx + xx;
         const int bi = p_brick_index[mi];
@@ -666,7 +671,8 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
         if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
         else       hipLaunchKernelGGL((k_fill<NV, false, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
     } else {
-        hipLaunchKernelGGL((k_fill_finish<NV>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        hipLaunchKernelGGL((k_fill_finish<NV>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), c->finish_tau_all, c->finish_n_before,
+                           (size_t)c->g.Nx * NV * c->g.Ny * NV);
     }
     return VP_OK;
 }

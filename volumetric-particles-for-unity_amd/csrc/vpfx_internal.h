@@ -129,6 +129,8 @@ struct vp_ctx {
     float* d_depthmap = nullptr;
     bool have_depthmap = false;
     FillConsts fc{};
+    const float* finish_tau_all = nullptr;   // vp_fill_finish_gathered: [world][LH][LW] transmittance maps, only during that call
+    int finish_n_before = 0;
 
     // occluder boxes (scene-occlusion inputs produced on the GPU)
     vp_obb* d_occluders = nullptr;

@@ -162,6 +162,9 @@ class Engine:
     def fill_finish(self, d_light_in: int | None):
         self._ck(self.L.vp_fill_finish(self.h, C.c_void_p(d_light_in or 0)), "vp_fill_finish")
 
+    def fill_finish_gathered(self, d_tau_all: int, rank: int, world: int):
+        self._ck(self.L.vp_fill_finish_gathered(self.h, C.c_void_p(d_tau_all), int(rank), int(world)), "vp_fill_finish_gathered")
+
     def read_brick(self, xx, yy, zz):
         out = np.empty((self.nv, self.nv, self.nv, 4), dtype=np.uint16)
         self._ck(self.L.vp_read_brick(self.h, int(xx), int(yy), int(zz), _vp(out)), "vp_read_brick")

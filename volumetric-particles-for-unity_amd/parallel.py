@@ -132,6 +132,10 @@ class SlabPipeline:
         if self._tau_all is None:
             self._tau_all = torch.empty((self.world,) + tuple(tau.shape), dtype=tau.dtype, device=tau.device)
         taus = self._all_gather(self._tau_all, tau)
+        if hasattr(self.eng, "fill_finish_gathered") and self._tau_all.is_contiguous():
+            # the product of the maps nearer the light is formed inside the finish kernel, straight from the receive buffer
+            self.eng.fill_finish_gathered(self._tau_all, self.rank, self.world)
+            return
         t_in = None
         for r in range(self.rank):                 # product in slab order, like the sequential light map
             t_in = taus[r].clone() if t_in is None else t_in.mul_(taus[r])
@@ -267,6 +271,9 @@ class HipSlabEngine:
 
     def fill_finish(self, t_in):
         self.e.fill_finish(None if t_in is None else t_in.contiguous().data_ptr())
+
+    def fill_finish_gathered(self, tau_all, rank, world):
+        self.e.fill_finish_gathered(tau_all.data_ptr(), rank, world)
 
     def z_boundary(self, cam):
         return self.e.z_boundary(cam)
