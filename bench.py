@@ -131,19 +131,21 @@ def main():
             dist.init_process_group(args.backend)
 
     sc = S.make_scene(args.config, cubemap=args.cubemap)
-    weights, whole_occupied = None, None
+    weights, fill_w, rm_w, whole_occupied = None, None, None, None
     if world > 1:
         # every rank computes the same (particle, MV)-pair histogram along the light axis (balanced slabs) and the
         # whole-grid occupancy (sizes the optional 1-GPU reference frame below); binning allocates no bricks
         probe = E.Engine(sc.config(device=local_rank))
         probe.set_frame(sc.light_to_world, sc.grid_center)
-        probe.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
-        if not args.uniform_slabs:
-            weights = [float(x) for x in probe.z_histogram()]
-        probe.bin_resident()
+        probe.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        counts = probe.bin_counts()
+        mvpos = probe.mv_positions()
         whole_occupied = probe.stats()["occupied_mv"]
         probe.close()
-    bounds = PAR.slab_bounds(sc.N[2], world, weights)
+        if not args.uniform_slabs:
+            # estimated ms per light-axis slice: fill (~ pairs) + this camera's ray-march (~ screen footprint of the occupied MVs)
+            weights, fill_w, rm_w = PAR.slice_costs(counts, mvpos, sc.cam_pos, sc.mv_scale, sc.height, np.radians(sc.fov_y_deg), sc.steps)
+    bounds = PAR.choose_slabs(sc.N[2], world, fill_w, rm_w) if weights is not None else PAR.slab_bounds(sc.N[2], world, None)
     # strong scaling: the unit of work is the SINGLE-GPU job (its voxels and its executed samples).  Sharded runs execute
     # more lattice samples in total (the saturation early-out only sees one slab), which must not inflate `value`.
     ref_units, ref_image, ref_skipped = None, None, None

@@ -98,3 +98,28 @@ def test_weighted_slabs_minimise_the_heaviest_slab():
         b = PAR.slab_bounds(nz, world, w)
         _check_partition(b, nz, world)
         assert max(sum(w[z0:z1]) for z0, z1 in b) <= best * (1 + 1e-12) + 1e-12
+
+
+def test_choose_slabs_minimises_the_sum_of_stage_maxima_over_its_candidates():
+    import random
+    rng = random.Random(3)
+    for _ in range(30):
+        nz, world = rng.randint(4, 32), rng.choice([2, 3, 4, 8])
+        if world > nz:
+            continue
+        fill = [rng.random() for _ in range(nz)]
+        rm = [4 * rng.random() * (nz - z) / nz for z in range(nz)]          # camera on the light side: near slices cost more
+        b = PAR.choose_slabs(nz, world, fill, rm)
+        _check_partition(b, nz, world)
+        cost = lambda bb: 1.3 * max(sum(fill[a:c]) for a, c in bb) + max(sum(rm[a:c]) for a, c in bb)
+        for alt in (PAR.slab_bounds(nz, world, fill), PAR.slab_bounds(nz, world, rm), PAR.slab_bounds(nz, world, [f + r for f, r in zip(fill, rm)])):
+            assert cost(b) <= cost(alt) + 1e-12
+
+
+def test_slice_costs_weigh_near_metavoxels_more():
+    import numpy as np
+    cnt = np.ones((4, 2, 2), dtype=np.int32)
+    pos = np.zeros((4, 2, 2, 3))
+    pos[..., 2] = np.arange(4)[:, None, None] * 3.0 + 10.0                   # slices at distance 10, 13, 16, 19 from a camera at the origin
+    w, f, r = PAR.slice_costs(cnt, pos, (0, 0, 0), 3.0, 1080, np.radians(60.0), 64)
+    assert f[0] == f[3] and r[0] > r[1] > r[2] > r[3] and abs(r[0] / r[3] - (19.0 / 10.0) ** 2) < 0.05

@@ -83,6 +83,13 @@ __device__ __forceinline__ void wait_vm_dyn(int i, f32x4& q)
 #ifndef VPFX_FILL_DIRECT_ACC
 #define VPFX_FILL_DIRECT_ACC 1
 #endif
+// A/B switch for the north_star's "scattered into LDS-resident voxel tiles" (SURVEY section 7): 1 / 2 keep the wave's (density, ao)
+// tile -- CH slices x 64 columns x 2 floats = 16 KB -- in LDS instead of registers and scatter into it particle by particle (1:
+// read + add + write, deterministic order; 2: ds_add_f32, the LDS float atomic); 0 (product) = register arrays.  Global-table
+// kernel only (the LDS cube map leaves no room for tiles).  Measured at C3: see DESIGN.md section 10.
+#ifndef VPFX_FILL_LDS_TILE
+#define VPFX_FILL_LDS_TILE 0
+#endif
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -283,7 +290,14 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 
 #pragma unroll 1
         for (int c0 = 0; c0 < NV; c0 += CH) {
-#if VPFX_FILL_DIRECT_ACC
+#if VPFX_FILL_LDS_TILE
+            extern __shared__ float lds_tile_all[];                                      // [wave][2][CH][64]
+            float* lds_dens = lds_tile_all + (threadIdx.x >> 6) * (2 * CH * 64) + lane;
+            float* lds_ao = lds_dens + CH * 64;
+#pragma unroll
+            for (int s = 0; s < CH; ++s) { lds_dens[s * 64] = 0.f; lds_ao[s * 64] = 0.f; }
+            struct { float* p; __device__ float operator[](int s) const { return p[s * 64]; } } dens{lds_dens}, ao{lds_ao};
+#elif VPFX_FILL_DIRECT_ACC
             typename AccArr<CH>::type dens, ao;
             AccArr<CH>::clear(dens, ao);                                                 // "clear it"  :178-181
 #else
@@ -383,7 +397,13 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         if constexpr (TAB == 0) qf = make_float4(q[0], q[1], q[2], q[3]);
                         else qf = make_float4((float)q.a, (float)q.b, (float)q.c, (float)q.d);   // bytes 0..255; 1/255 is folded into Dk
                         cube_shade<EXACT>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk);
-#if VPFX_FILL_DIRECT_ACC
+#if VPFX_FILL_LDS_TILE == 1
+                        lds_dens[s * 64] += den;                                         // ds_read_b32, v_add_f32, ds_write_b32
+                        atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));   // ds_max_i32
+#elif VPFX_FILL_LDS_TILE == 2
+                        atomicAdd(lds_dens + s * 64, den);                               // ds_add_f32
+                        atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));
+#elif VPFX_FILL_DIRECT_ACC
                         AccArr<CH>::add_max(dens, ao, s, den, net);                      // :200-201
 #else
                         dens[s] += den;                                                  // :200
@@ -663,13 +683,18 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 {
     constexpr int TPM = (NV / 16) * (NV / 16);
     const dim3 grid(c->g.Nx * c->g.Ny * TPM), block(256);
+#if VPFX_FILL_LDS_TILE
+    static const int dbg_lds = 4 * 2 * (NV < 32 ? NV : 32) * 64 * (int)sizeof(float);        // the four waves' (density, ao) tiles
+#else
     static const int dbg_lds = getenv("VPFX_FILL_LDS") ? atoi(getenv("VPFX_FILL_LDS")) : 0;   // occupancy experiments only
+#endif
+    const int tl = VPFX_FILL_LDS_TILE ? dbg_lds : 0;
     if (mode == 0) {
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
         else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, dbg_lds, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
     } else if (mode == 1) {
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
-        else       hipLaunchKernelGGL((k_fill<NV, false, 1>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        else       hipLaunchKernelGGL((k_fill<NV, false, 1>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
     } else {
         hipLaunchKernelGGL((k_fill_finish<NV>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), c->finish_tau_all, c->finish_n_before,
                            (size_t)c->g.Nx * NV * c->g.Ny * NV);

@@ -70,6 +70,42 @@ def slab_bounds(nz: int, world: int, weights: Sequence[float] | None = None) -> 
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def slice_costs(bin_counts, mv_positions, cam_pos, mv_scale: float, height: int, fov_y_rad: float, steps_per_mv: int,
+                ms_per_pair: float = 7.3e-6, samples_per_ms: float = 2.0e8):
+    """Estimated milliseconds of work per light-axis slice zz, the weights `slab_bounds` cuts balanced slabs from:
+      fill       ~ (particle, MV) pairs of the slice                      (k_fill is linear in them: 3.5 ms / 480 k pairs at C3)
+      ray-march  ~ lattice samples the slice's occupied MVs receive = screen footprint of each MV (pixels, ~ (focal * s / distance)^2:
+                   MVs near the camera cost up to 8x the far ones at the benchmark camera) x samples on the chord through it
+                   (steps / sqrt(3) per MV unit, mean chord of a unit cube ~ 2/3 ... 1).  A slab cannot know that rays are already
+                   saturated by slabs in front of it, so every occupied MV counts.
+    bin_counts [Nz,Ny,Nx] ints, mv_positions [Nz,Ny,Nx,3]; host-side numpy, no device work."""
+    import numpy as np
+    cnt = np.asarray(bin_counts)
+    occ = cnt != 0
+    d = np.linalg.norm(np.asarray(mv_positions, dtype=np.float64) - np.asarray(cam_pos, dtype=np.float64), axis=-1)
+    focal_px = 0.5 * height / np.tan(0.5 * fov_y_rad)
+    area_px = (focal_px * mv_scale / np.maximum(d, 0.5 * mv_scale)) ** 2 * 1.5          # silhouette of a cube seen off-axis ~ 1.5 faces
+    samples = area_px * (steps_per_mv / 1.73205) * 0.75
+    rm_ms = (samples * occ).sum(axis=(1, 2)) / samples_per_ms
+    fill_ms = cnt.sum(axis=(1, 2)).astype(np.float64) * ms_per_pair
+    return [float(x) for x in (fill_ms + rm_ms)], [float(x) for x in fill_ms], [float(x) for x in rm_ms]
+
+
+def choose_slabs(nz: int, world: int, fill_ms: Sequence[float], rm_ms: Sequence[float]) -> List[Tuple[int, int]]:
+    """Slab cut for the two-stage pipeline.  The stages are separated by collectives, so a frame costs
+    max_r(fill_r) * 1.3 (local + finish pass) + max_r(raymarch_r): the cut that balances the SUM per slice need not minimise
+    that.  Candidates = optimal contiguous partitions of fill + alpha * raymarch for a few alpha (0 = fill only ... inf = ray-march
+    only); the one with the smallest stage-maxima sum wins (ties: the earliest candidate, i.e. the more fill-balanced)."""
+    best, best_t = None, float("inf")
+    for alpha in (0.0, 0.25, 0.5, 1.0, 2.0, 4.0, None):
+        w = [r if alpha is None else f + alpha * r for f, r in zip(fill_ms, rm_ms)]
+        b = slab_bounds(nz, world, w)
+        t = 1.3 * max(sum(fill_ms[z0:z1]) for z0, z1 in b) + max(sum(rm_ms[z0:z1]) for z0, z1 in b)
+        if t < best_t - 1e-12:
+            best, best_t = b, t
+    return best
+
+
 def blend_plan(bounds: Sequence[Tuple[int, int]], z_boundary: int):
     """Which partial images exist and the order they are blended in (slab granularity of VPR.cs:652-711).
     Returns (plan, straddler): plan = list of (rank, which, kind) with which in {"over","under"}, kind 0 = OVER,
