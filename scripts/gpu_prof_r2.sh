@@ -2,7 +2,7 @@
 # --kernel-trace --stats first, then PMC counters in separate passes (never combined with other trace domains).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r2
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_DIR:-prof_r2}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS}"
@@ -17,6 +17,6 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ
 done
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $OUT/kt/kt_results.db $OUT/pmc*/pmc*_results.db > $OUT/summary.txt 2>&1
 grep -h "^{\"metric\"" $OUT/kt_bench.log | tail -1 > $OUT/bench_line.json
-python $GRAFT_REPO_ROOT/scripts/traffic_json.py $OUT/pmc3/pmc3_results.db $OUT/pmc4/pmc4_results.db $OUT/traffic.json > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/scripts/traffic_json.py $OUT/pmc3/pmc3_results.db $OUT/pmc4/pmc4_results.db $OUT/traffic.json > $OUT/traffic.log 2>&1
 rm -rf $OUT/*/*.db
 grep -E "k_fill|k_raymarch" $OUT/summary.txt | grep -v "k_fill_value\|k_fill_finish" | cut -c1-140 | head -80

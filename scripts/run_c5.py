@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package; load_package()
 from vpfx_amd import scene as S, engine as E
-sc = S.make_scene("C5")
+sc = S.make_scene("C5", cubemap=(sys.argv[1] if len(sys.argv) > 1 else "r8"))
 e = E.Engine(sc.config())
 e.set_frame(sc.light_to_world, sc.grid_center)
 e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
