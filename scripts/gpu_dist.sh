@@ -1,7 +1,19 @@
+# functional multi-rank runs of bench.py on ONE GPU (all ranks share cuda:0, gloo moves the tensors through host memory):
+# checks the whole N > 1 code path (slab cut, split fill with the fused tau product, partial ray-march, both exchanges, shard check)
 cd $GRAFT_REPO_ROOT
-echo "--- torchrun nproc 1"
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --config C1 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-400
-echo "--- 2 ranks sharing one GPU over gloo (functional)"
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 3 --warmup 1 --config C1 --backend gloo --share-gpu 2>&1 | tail -4 | cut -c1-900
-echo "--- 4 ranks"
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 4 --steps 3 --warmup 1 --config C2 --backend gloo --share-gpu 2>&1 | tail -3 | cut -c1-900
+export MASTER_ADDR=127.0.0.1
+for n in 2 4 8; do
+  for ex in tiles all_gather; do
+    echo "== $n ranks, exchange $ex"
+    timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --steps 3 --warmup 1 \
+      --backend gloo --share-gpu --exchange $ex --config ${CFG:-C3} 2>&1 | grep -E '^\{"metric"|Error|error|Traceback' | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); c = d['config']
+        print('ms/step', round(d['ms_per_step'], 2), 'slabs', c['slabs'], 'max|dRGBA| vs 1-GPU frame', c['max_abs_rgba_diff_vs_1gpu_frame'], 'skipped', c['reference_frame_skipped'])
+    else:
+        print(l.strip()[:200])
+"
+  done
+done

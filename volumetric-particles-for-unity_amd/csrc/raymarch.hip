@@ -409,10 +409,10 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #define VPFX_RM_WAVES 4      // 115 VGPRs, no scratch (5 waves = 96 VGPRs spills 13 registers: measured 1.63 vs 1.58 ms at C3)
 #endif
 #ifndef VPFX_RM_WAVES_PARTIAL
-#define VPFX_RM_WAVES_PARTIAL VPFX_RM_WAVES
+#define VPFX_RM_WAVES_PARTIAL 3   // partial images + flag paths (debug views of a slab): the one combination that needs > 128 VGPRs
 #endif
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
-__global__ void __launch_bounds__(64, (PARTIAL || FLAGS) ? VPFX_RM_WAVES_PARTIAL : VPFX_RM_WAVES)
+__global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : VPFX_RM_WAVES)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
@@ -485,7 +485,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         if (!(ta <= tb)) continue;
         const bool phaseA = zz <= k.zB;                                                    // VPR.cs:667 vs :697
         const bool over = FLAGS && phaseA;                                                 // literal OVER, cells far -> near
-        F4& d = (PARTIAL && !phaseA) ? dstB : dstA;
+        F4 d = (PARTIAL && !phaseA) ? dstB : dstA;        // by value (written back below): a selected reference would put both images on the stack
         const int* occ = brick_index + zz * nxy;
         int last = over ? 0x7fffffff : -1;
         // Walk of the (x,y) cells the ray crosses inside this slab, t in [ta, tb]: an integer DDA -- the cell index is stepped
@@ -510,31 +510,32 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         };
         const int max_cells = 2 * (k.Nx + k.Ny) + 8;
         // The reference's order inside a slab is the GLOBAL (x,y) sort (rank), not the order along this ray.  Almost always
-        // the two agree (ranks ascend along the ray): one look-ahead walk checks that, and the cells are then marched as a
-        // second walk meets them -- O(cells) instead of one selection walk per cell (O(cells^2): a ray running along a slab
-        // crosses up to Nx + Ny cells).  Otherwise, and for the literal OVER order, fall back to selection by rank.
+        // the two agree (ranks ascend along the ray), so the cells are marched optimistically as ONE walk meets them -- O(cells)
+        // instead of one selection walk per cell (O(cells^2): a ray running along a slab crosses up to Nx + Ny cells).  If an
+        // occupied cell turns up whose rank is below the last one marched, the order was not the ray's: the slab's blends are
+        // rolled back (dst and the sample count as they were at the slab's start) and the slab is redone with selection by rank,
+        // which the literal OVER order always uses.  (A separate look-ahead walk checking the ranks first cost 3.6 % of the kernel.)
         bool stream = !over;
-        if (stream) {
-            int cx, cy, prev = -1;
-            walk_start(cx, cy);
-            bool fin = false;
-            for (int guard = 0; guard < max_cells && !fin; ++guard) {
-                const int cell = walk_step(cx, cy, fin);
-                if (cell >= 0 && occ[cell] >= 0) { const int r = rank[cell]; if (r < prev) stream = false; prev = r; }
-            }
-        }
+        const F4 d_start = d;
+        const int ns_start = nsamp;
         int wcx, wcy, walked = 0;                               // streaming walk
         walk_start(wcx, wcy);
         bool wfin = false;
         for (;;) {
             int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
             if (stream) {
-                // next occupied cell along the ray (ranks ascend)
+                // next occupied cell along the ray
                 while (!wfin && walked < max_cells) {
                     const int cell = walk_step(wcx, wcy, wfin);
                     ++walked;
-                    if (cell >= 0 && occ[cell] >= 0) { const int r = rank[cell]; if (r > last) { best_r = r; best_cell = cell; break; } }
+                    if (cell >= 0 && occ[cell] >= 0) {
+                        const int r = rank[cell];
+                        if (r > last) { best_r = r; best_cell = cell; }
+                        else { d = d_start; nsamp = ns_start; stream = false; last = -1; }     // ranks do not ascend along this ray: redo
+                        break;
+                    }
                 }
+                if (!stream) continue;
             } else {
                 // select the next occupied cell of this slab: rank ascending = near -> far (descending for the literal OVER order)
                 int cx, cy;
@@ -573,6 +574,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         }
         // saturated: everything farther along the ray is multiplied by (1 - dst.a) == 0.  (A saturated phase-A image of a slab
         // also hides the slab's own phase-B image, which is composited behind it.)
+        if (PARTIAL && !phaseA) dstB = d; else dstA = d;
         if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
     }
 
