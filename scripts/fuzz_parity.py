@@ -58,6 +58,13 @@ def make_case_scene(seed):
         sd = np.full((H, W), 1.0e30, dtype=np.float32)
         sd[: H // 2] = np.float32(D * rng.uniform(0.3, 1.2))
         sc.scene_depth = sd
+    # (drawn last, so the scenes of earlier sweeps keep their seeds) 40 %: an 8-bit cube map of a random size -- the LDS-resident
+    # path of the default-math fill (immediate pitch at S = 128, generic otherwise, global-table fallback above S = 163)
+    r8 = np.random.default_rng(seed + 977)
+    if r8.random() < 0.4:
+        size = int(r8.choice([128, 128, int(r8.integers(2, 164)), int(r8.integers(164, 220))]))
+        sc.cubemap = np.ascontiguousarray(r8.integers(0, 256, size=(6, size, size), dtype=np.uint8))
+        sc.displacement_scale = float(r8.choice([0.7, 0.7, r8.uniform(0.0, 1.0), 1.0]))
     return sc, rng
 
 
@@ -75,12 +82,20 @@ def one_case(seed):
         x.fill(sc.fill_params())
     co = o.bin_counts()
     assert np.array_equal(co, g.bin_counts()), "bin counts"
-    worst = 0
+    worst, worst_abs = 0, 0.0
     for zz, yy, xx in zip(*np.nonzero(co)):
-        a, b = o.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32), g.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32)
-        worst = max(worst, int(np.abs(a - b).max()))
-    assert worst <= (0 if exact else 1), f"brick ulp {worst} (exact={exact})"
-    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+        fa, fb = o.read_brick(xx, yy, zz), g.read_brick(xx, yy, zz)
+        a, b = fa.view(np.uint16).astype(np.int32), fb.view(np.uint16).astype(np.int32)
+        du = np.abs(a - b)
+        worst = max(worst, int(du.max()))
+        if not exact and du.max() > 1:
+            worst_abs = max(worst_abs, float(np.abs(fa.astype(np.float32) - fb.astype(np.float32))[du > 1].max()))
+    # EXACT math: bit-identical.  Default math (v_rcp_f32 in the cube addressing and the smoothstep): <= 1 fp16 ulp -- except that
+    # with a white-noise cube map and displacement scale near 1 (net displacement near 0) the smoothstep's t = 10/3 - (40/3) d2/net
+    # amplifies the reciprocal's last bit, which shows in near-zero densities (1e-4, a dozen fp16 ulp = 1e-6 absolute); bounded
+    # absolutely there.  Both table paths (LDS bytes, global floats) deviate identically.
+    assert worst <= (0 if exact else 1) or (not exact and worst_abs <= 2e-5), f"brick ulp {worst} abs {worst_abs:.2e} (exact={exact})"
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5 if exact else 5e-5, atol=1e-9)
     cam, rp = sc.camera(), sc.raymarch_params()
     io, ig, ie = o.raymarch(cam, rp), g.raymarch(cam, rp), ge.raymarch(cam, rp)
     err, err_e = float(np.abs(io - ig).max()), float(np.abs(io - ie).max())
@@ -116,7 +131,7 @@ def one_case(seed):
         img = engs[0].blend([parts[(r, w)] for r, w, _ in plan], [kk for _, _, kk in plan]).cpu().numpy()
         err_s = float(np.abs(img - io).max())
         assert err_s <= 1e-3, f"slabs({world}) rgba {err_s}"
-        np.testing.assert_allclose(engs[-1].e.read_lightmap(), o.read_lightmap(), rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(engs[-1].e.read_lightmap(), o.read_lightmap(), rtol=2e-5 if exact else 6e-5, atol=1e-9)
         for h in engs:
             h.e.close()
         rq = sc.raymarch_params()
@@ -140,7 +155,7 @@ def one_case(seed):
             x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
             x.fill(sc.fill_params())
         assert np.array_equal(o.bin_counts(), g.bin_counts()), "frame 2: bin counts"
-        np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5 if exact else 5e-5, atol=1e-9)
         i2o, i2g = o.raymarch(cam2, rp2), g.raymarch(cam2, rp2)
         assert float(np.abs(i2o - i2g).max()) <= 1e-3 and o.stats()["samples"] == g.stats()["samples"], "frame 2"
     for x in (g, ge):

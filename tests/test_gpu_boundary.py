@@ -55,6 +55,28 @@ def test_r8_cubemap_matches_the_oracle_fed_the_same_bytes(D):
     np.testing.assert_array_equal(g2.raymarch(sc2.camera(), sc2.raymarch_params()), ig)
 
 
+def test_displacement_scale_one_on_zero_texels_default_math():
+    """D = 1 on texels that are exactly 0 makes netDisplacement 0: smoothstep(0, 0, x) = saturate(x / +0) = 1 in the reference
+    (density = opacityFactor).  The default-math kernels must reproduce that discontinuity too (found by scripts/fuzz_parity.py)."""
+    for fmt in ("r8", "f32"):
+        sc = S.make_scene("T0")
+        cube = r8_cubemap(32, 11)
+        cube[:, ::2, :] = 0                                   # half of the rows all zero: many all-zero bilinear quads
+        cube[2] = 0
+        sc.cubemap = cube if fmt == "r8" else np.ascontiguousarray(cube.astype(np.float32) / np.float32(255.0))
+        sc.displacement_scale = 1.0
+        o, g = both(sc)                                       # default math (LDS path for r8, global table for f32)
+        cnt = o.bin_counts()
+        hit_zero = 0
+        for zz, yy, xx in zip(*np.nonzero(cnt)):
+            fa, fb = o.read_brick(xx, yy, zz), g.read_brick(xx, yy, zz)
+            du = np.abs(fa.view(np.uint16).astype(np.int32) - fb.view(np.uint16).astype(np.int32))
+            bad = du > 1
+            assert not bad.any() or float(np.abs(fa.astype(np.float32) - fb.astype(np.float32))[bad].max()) <= 2e-5, (fmt, xx, yy, zz)
+            hit_zero += int((fa[..., 3] >= np.float16(sc.opacity_factor * 0.999)).sum())
+        assert hit_zero > 100                                  # the scene really has voxels at full opacityFactor
+
+
 def test_r8_cubemap_default_math_within_one_fp16_ulp():
     sc = S.make_scene("T0")
     sc.cubemap = r8_cubemap(64, 9)

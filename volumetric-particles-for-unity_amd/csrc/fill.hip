@@ -220,8 +220,13 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
         t = (d2q - net) / (0.7f * net - net);                                     // smoothstep(net, 0.7 net, d2q) :126
         t = fminf(fmaxf(t, 0.f), 1.f);
     } else {
-        // same quantity, (4 d2 - net) / (-0.3 net) = 10/3 - (40/3) d2 / net, as reciprocal + multiply + fused clamp
-        t = __builtin_amdgcn_fmed3f(fmaf(d2 * __builtin_amdgcn_rcpf(net), -13.333333f, 3.3333333f), 0.f, 1.f);
+        // same quantity, (4 d2 - net) / (-0.3 net) = 10/3 - (40/3) d2 / net, as reciprocal + multiply + fused clamp.  One input
+        // needs the quotient form: displacement scale exactly 1 makes net == 0 on a zero texel, where the reference's
+        // (x - net) / (0.7 net - net) is x / +0 = +inf -> saturate 1 (density = opacityFactor; 0 / 0 saturates to 0) while
+        // 10/3 - (40/3) d2 / 0 would give 0.  (4 d2 - net) * rcp(fma(net, 0.7, -net)) keeps the sign of that zero; it costs 3 % of
+        // the kernel, so it is only taken when D == 1 (a wave-uniform integer flag: scalar compare + branch).
+        if (f.d_is_one) t = __builtin_amdgcn_fmed3f(fmaf(d2, 4.0f, -net) * __builtin_amdgcn_rcpf(fmaf(net, 0.7f, -net)), 0.f, 1.f);
+        else            t = __builtin_amdgcn_fmed3f(fmaf(d2 * __builtin_amdgcn_rcpf(net), -13.333333f, 3.3333333f), 0.f, 1.f);
     }
     // :126-127, :130-131: t*t*(3 - 2t) * opacityFactor * (fade ? opacity : 1).  opw = 1.0 exactly when _FadeOutParticles is off.
     // The fast path folds the wave-uniform factors into the cubic's coefficients (t*t) * (3k - 2k t), k = opacityFactor * opw.

@@ -102,6 +102,7 @@ void hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p)
     f.one_minus_D = 1.0f - p->displacement_scale;
     f.D_over_255 = p->displacement_scale / 255.0f;
     f.lds_pitch = c->cubeS + 2;
+    f.d_is_one = p->displacement_scale == 1.0f ? 1 : 0;
     f.init_light = p->init_light_intensity;
     for (int i = 0; i < 3; ++i) f.amb[i] = p->ambient[i];
     f.fade = p->fade_out_particles;

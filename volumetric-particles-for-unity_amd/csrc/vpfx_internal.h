@@ -47,6 +47,7 @@ struct FillConsts {
     int   border_index;           // nv - clamp(b, 0, nv-2)                                Fill.shader:229
     float D_over_255;             // displacement scale for byte texels (R8 cube map in LDS): net = (D/255) * bilinear(bytes) + (1 - D)
     int   lds_pitch;              // S + 2: row pitch of the padded byte table
+    int   d_is_one;               // displacement scale == 1 exactly (net displacement can be 0: see cube_shade)
 };
 
 struct RmConsts {
