@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--cubemap", default="r8", choices=["r8", "f32"],
                     help="displacement cube map texel format: r8 = 8-bit like the reference's asset (LDS-resident in k_fill), f32 = float texels")
     ap.add_argument("--no-lds-cubemap", action="store_true", help="A/B: keep an R8 cube map on the global f32 footprint table")
+    ap.add_argument("--no-grey", action="store_true", help="A/B: keep RGBA16F bricks although the ambient colour is grey")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
@@ -175,6 +176,8 @@ def main():
     cfg = sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0))
     if args.no_lds_cubemap:
         cfg.reserved[0] = 1            # VPFX_CFG_NO_LDS_CUBEMAP
+    if args.no_grey:
+        cfg.reserved[1] = 1            # VPFX_CFG_NO_GREY_BRICKS
     eng = E.Engine(cfg)
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
@@ -228,6 +231,7 @@ def main():
         fill_bytes = st["occupied_mv"] * (8 * nv ** 3 + 8 * nv ** 2) + 84 * st["pairs"]
         rm_bytes = st["bricks_sampled"] * 8 * nv ** 3 + 16 * sc.width * sc.height
         lds_path = args.cubemap == "r8" and not args.no_lds_cubemap
+        bpv = st.get("brick_bytes_per_voxel", 8)
         roofs = {
             "fill": {"bound": "hbm", "kernel": "k_fill_lds" if lds_path else "k_fill", "achieved": fill_bytes / (fill_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "bytes_per_launch": fill_bytes, "avg_ms": fill_ms},
@@ -283,6 +287,8 @@ def main():
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
                        "cubemap": ("R8 (8-bit like the reference's asset; LDS-resident in k_fill)" if args.cubemap == "r8" and not args.no_lds_cubemap
                                    else "R8 on the global f32 footprint table" if args.cubemap == "r8" else "f32 texels, global footprint table"),
+                       "brick_storage": ("luminance|density fp16 pairs, 4 B/voxel (grey ambient: r = g = b bit for bit); algorithmic bytes keep "
+                                         "SURVEY 8(d)'s 8 B/voxel RGBA16F definition" if bpv == 4 else "RGBA16F, 8 B/voxel"),
                        "parallelism": f"zslab{world}" + (f" ({args.exchange} exchange)" if world > 1 else ""), "slabs": bounds if world > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),

@@ -58,7 +58,8 @@ typedef struct vp_config {
     int32_t slab_z0, slab_z1; /* owned light-axis slab zz in [z0,z1); 0,0 = whole grid (1 GPU)    */
     int32_t exact_math;       /* 1: IEEE divisions in the fill kernel (bit-parity test builds)     */
     int32_t no_early_out;     /* 1: the ray-march never stops early (sample-count parity tests)    */
-    int32_t reserved[3];
+    int32_t reserved[3];      /* 0.  (Measurement switches: [0] = 1 keeps an R8 cube map out of LDS,
+                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey.)       */
 } vp_config;
 
 /* Byte layout of one caller-side particle record (ParticleSystem.Particle[], VPR.cs:412-413).
@@ -149,7 +150,9 @@ typedef struct vp_stats {
     int64_t brick_bytes;          /* resident brick pool bytes                                    */
     int64_t max_pairs_per_mv;
     int64_t bricks_sampled;       /* bricks that contributed >= 1 sample to the last vp_raymarch* call */
-    int64_t reserved[4];
+    int64_t brick_bytes_per_voxel;/* 8 = RGBA16F; 4 = (luminance, density) fp16 pairs: the storage the library picks when the
+                                     ambient colour is grey (r = g = b in every voxel); vp_read_brick always returns RGBA16F */
+    int64_t reserved[3];
 } vp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -65,6 +65,8 @@ def make_case_scene(seed):
         size = int(r8.choice([128, 128, int(r8.integers(2, 164)), int(r8.integers(164, 220))]))
         sc.cubemap = np.ascontiguousarray(r8.integers(0, 256, size=(6, size, size), dtype=np.uint8))
         sc.displacement_scale = float(r8.choice([0.7, 0.7, r8.uniform(0.0, 1.0), 1.0]))
+    if r8.random() < 0.3:       # a coloured ambient keeps RGBA16F bricks (grey ambient: luminance | density storage)
+        sc.ambient = tuple(float(x) for x in r8.uniform(0.0, 0.5, 3))
     return sc, rng
 
 

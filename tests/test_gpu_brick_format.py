@@ -1,0 +1,94 @@
+"""GPU: the two brick storage formats.  With a grey ambient colour (the reference's default, scene:9021) every voxel has r = g = b
+bit for bit (diffuse is the scalar 0.4 T, Fill.shader:239-241), and the library stores (luminance, density) fp16 pairs -- 4 bytes per
+voxel -- instead of RGBA16F; a coloured ambient keeps RGBA16F.  Both must be the oracle's bricks and image, and on a grey scene both
+formats must give the SAME bricks (as read through vp_read_brick) and the same image bit for bit."""
+import numpy as np
+import pytest
+
+from vpfx_amd import abi, engine as E, scene as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run(sc, rgba_only=False, **kw):
+    cfg = sc.config()
+    if rgba_only:
+        cfg.reserved[1] = 1                    # VPFX_CFG_NO_GREY_BRICKS
+    g = E.Engine(cfg, **kw)
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    g.fill(sc.fill_params())
+    return g
+
+
+def oracle(sc):
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    return o
+
+
+@pytest.mark.parametrize("dims", [(4, 16, 120, 96, 64), (6, 32, 400, 160, 120), (3, 64, 40, 96, 64)])
+@pytest.mark.parametrize("cubemap", ["f32", "r8"])
+def test_grey_and_rgba_storage_are_the_same_bricks_and_image(dims, cubemap):
+    sc = S.make_scene("g", dims=dims, cubemap=cubemap)
+    a, b = run(sc, early_out=False), run(sc, rgba_only=True, early_out=False)
+    assert a.stats()["brick_bytes_per_voxel"] == 4 and b.stats()["brick_bytes_per_voxel"] == 8
+    cnt = a.bin_counts()
+    for zz, yy, xx in zip(*np.nonzero(cnt)):
+        assert np.array_equal(a.read_brick(xx, yy, zz).view(np.uint16), b.read_brick(xx, yy, zz).view(np.uint16)), (xx, yy, zz)
+    np.testing.assert_array_equal(a.read_lightmap(), b.read_lightmap())
+    ia, ib = a.raymarch(sc.camera(), sc.raymarch_params()), b.raymarch(sc.camera(), sc.raymarch_params())
+    np.testing.assert_array_equal(ia, ib)
+    assert a.stats()["samples"] == b.stats()["samples"]
+    o = oracle(sc)
+    assert np.abs(ia - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
+    assert o.stats()["samples"] == a.stats()["samples"]
+    # debug / UNORM8 flag kernels and the literal-order path read the grey bricks too
+    for flags in (abi.VP_RM_QUANTIZE_UNORM8, abi.VP_RM_SHOW_NUM_SAMPLES):
+        rp = sc.raymarch_params()
+        rp.flags = flags
+        np.testing.assert_array_equal(a.raymarch(sc.camera(), rp), b.raymarch(sc.camera(), rp))
+
+
+@pytest.mark.parametrize("ambient", [(0.3, 0.2, 0.1), (0.0, 0.5, 0.25)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_coloured_ambient_keeps_rgba_bricks_and_matches_the_oracle(ambient, exact):
+    sc = S.make_scene("c", dims=(6, 16, 300, 96, 64))
+    sc.ambient = ambient
+    g = run(sc, exact=exact, early_out=False)
+    assert g.stats()["brick_bytes_per_voxel"] == 8
+    o = oracle(sc)
+    cnt = o.bin_counts()
+    for zz, yy, xx in zip(*np.nonzero(cnt)):
+        a, b = o.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32), g.read_brick(xx, yy, zz).view(np.uint16).astype(np.int32)
+        assert np.abs(a - b).max() <= (0 if exact else 1), (xx, yy, zz)
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ig).max() <= 1e-3 and o.stats()["samples"] == g.stats()["samples"]
+    assert np.abs(ig[..., 0] - ig[..., 1]).max() > 1e-3           # the image really is coloured
+
+
+def test_border_zero_keeps_rgba_bricks():
+    sc = S.make_scene("b0", dims=(4, 16, 150, 96, 64), border=0)   # wrap-around filtering: RGBA sampling path only
+    g = run(sc)
+    assert g.stats()["brick_bytes_per_voxel"] == 8
+    o = oracle(sc)
+    assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
+
+
+def test_format_follows_the_ambient_colour_from_fill_to_fill():
+    sc = S.make_scene("T0")
+    g = run(sc)
+    assert g.stats()["brick_bytes_per_voxel"] == 4
+    sc.ambient = (0.3, 0.2, 0.1)
+    g.fill(sc.fill_params())
+    assert g.stats()["brick_bytes_per_voxel"] == 8
+    o = oracle(sc)
+    assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
+    sc.ambient = (0.2, 0.2, 0.2)
+    g.fill(sc.fill_params())
+    assert g.stats()["brick_bytes_per_voxel"] == 4
+    o = oracle(sc)
+    assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3

@@ -132,7 +132,8 @@ class vp_stats(C.Structure):
         ("brick_bytes", C.c_int64),
         ("max_pairs_per_mv", C.c_int64),
         ("bricks_sampled", C.c_int64),
-        ("reserved", C.c_int64 * 4),
+        ("brick_bytes_per_voxel", C.c_int64),
+        ("reserved", C.c_int64 * 3),
     ]
 
 

@@ -694,6 +694,20 @@ VP_EXPORT int vp_read_brick(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, uint1
     int bi = -1;
     VP_HIP(hipMemcpy(&bi, c->d_brick_index + mi, sizeof(int), hipMemcpyDeviceToHost));
     if (bi < 0) return vp_fail(c, VP_ERR_STATE, "metavoxel (%d,%d,%d) is empty / not owned: no brick", xx, yy, zz);
+    if (c->bricks_grey) {
+        // (luminance, density) storage: expand to the reference's RGBA16F texel (r = g = b = luminance, a = density)
+        const size_t n = nv3(c);
+        uint32_t* tmp = (uint32_t*)malloc(n * sizeof(uint32_t));
+        if (!tmp) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
+        hipError_t e = hipMemcpy(tmp, reinterpret_cast<const uint32_t*>(c->d_bricks) + (size_t)bi * n, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+            const uint16_t lum = (uint16_t)(tmp[i] & 0xffffu), den = (uint16_t)(tmp[i] >> 16);
+            half_rgba[4 * i] = lum; half_rgba[4 * i + 1] = lum; half_rgba[4 * i + 2] = lum; half_rgba[4 * i + 3] = den;
+        }
+        free(tmp);
+        if (e != hipSuccess) return vp_fail(c, VP_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+        return VP_OK;
+    }
     VP_HIP(hipMemcpy(half_rgba, c->d_bricks + (size_t)bi * nv3(c), nv3(c) * sizeof(uint2), hipMemcpyDeviceToHost));
     return VP_OK;
 }
@@ -722,7 +736,8 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
         st->max_pairs_per_mv = c->h_meta.max_pairs;
         st->voxels_filled = (int64_t)c->h_meta.occupied * (int64_t)nv3(c);
     }
-    st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));
+    st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));      // pool as allocated (grey bricks use the first half of it)
+    st->brick_bytes_per_voxel = c->bricks_grey ? 4 : 8;                                // bytes per voxel of the bricks as last filled
     VP_HIP(hipStreamSynchronize(c->stream));
     unsigned long long s = 0;
     VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));

@@ -29,6 +29,13 @@
 #ifndef VPFX_FILL_PIPE_LDS
 #define VPFX_FILL_PIPE_LDS 2  // slices in flight on the LDS-resident cube map (4 ds_read_u8 each; lgkmcnt holds 15)
 #endif
+// Row pitch of the LDS byte table.  The four byte reads of a wave-gather sit ~5 texels apart across the 8x8 lanes; with the natural pitch
+// S + 2 = 130 the 4 rows of a 32-lane group start 2.5 banks apart and collide 3-4-way (SQ_LDS_BANK_CONFLICT = 3/4 of the LDS cycles).
+#ifndef VPFX_LDS_PITCH_128
+#define VPFX_LDS_PITCH_128 136      // measured 130 / 132 / 136 / 140 / 144: 3.50 / 3.48 / 3.45 / 3.52 / 3.49 ms at C3
+#endif
+#define VPFX_STR2(x) #x
+#define VPFX_STR(x) VPFX_STR2(x)
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
 #endif
@@ -201,9 +208,10 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     // 8 ((face (S+1) + y0 + 1)(S+2) + x0 + 1), is formed in float as three FMAs (exact: small integers) + one conversion.
     const float S2f = Sf + 2.0f;
     if (TAB == 0) return (unsigned)fmaf(fid, 8.0f * ((Sf + 1.0f) * S2f), fmaf(y0, 8.0f * S2f, fmaf(x0, 8.0f, 8.0f * (S2f + 1.0f))));
-    // LDS table: bytes [face][S+2][S+2] with the clamp border replicated; byte address (face (S+2) + y0 + 1)(S+2) + x0 + 1 + base,
-    // lds_bias = S + 3 + base (exact in float: < 2^24)
-    return (unsigned)fmaf(fid, S2f * S2f, fmaf(y0, S2f, x0 + lds_bias));
+    // LDS table: bytes [face][S+2][pitch] with the clamp border replicated; byte address (face (S+2) + y0 + 1) pitch + x0 + 1 + base,
+    // lds_bias = pitch + 1 + base (exact in float: < 2^24)
+    const float pf = (float)f.lds_pitch;
+    return (unsigned)fmaf(fid, S2f * pf, fmaf(y0, pf, x0 + lds_bias));
 }
 
 template <bool EXACT>
@@ -254,7 +262,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
     constexpr int PIPE = TAB == 0 ? VPFX_FILL_PIPE : VPFX_FILL_PIPE_LDS;   // footprint loads in flight per wave
     static_assert(TAB == 0 || !EXACT, "the LDS (R8) path is default-math only: EXACT keeps the oracle's f32 table arithmetic");
-    const float lds_bias = f.half_s + f.half_s + 3.0f + (float)lds_base;
+    const float lds_bias = (float)(f.lds_pitch + 1) + (float)lds_base;
     const float Dk = TAB == 0 ? f.D : f.D_over_255;
     const int LW = g.Nx * NV;
     const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
@@ -386,7 +394,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
                     } else if constexpr (TAB == 1) {
                         const unsigned off = VPFX_FILL_LDS_SELECT ? (hit ? qi : lds_base) : qi;   // lanes without a covered voxel all read byte 0 (a broadcast)
-                        asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:130\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:131"
+                        asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "+1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
                     } else {
                         const unsigned off = hit ? qi : lds_base;
@@ -463,23 +471,34 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             }
 
             // propagate + store this chunk                                               Fill.shader:231-269
+            // volumeTex[int3(xy, slice)]: RGBA16F, or -- grey ambient: r = g = b bit for bit -- luminance | density, 4 bytes per voxel.
+            // The format is wave-uniform: the branch is taken once per chunk, outside the 32 unrolled slices.
+            auto propagate_store = [&](auto grey_tag) {
+                constexpr bool GREYB = decltype(grey_tag)::value;
+                uint32_t* brick32 = reinterpret_cast<uint32_t*>(p_bricks) + (size_t)bi * NV * NV * NV;
 #pragma unroll
-            for (int s = 0; s < CH; ++s) {
-                const int sg = c0 + s;
-                const bool inShadow = sg >= shadowIndex;
-                if (inShadow) T = 0.0f;
-                else if (sg < f.border_index) prop = T;
-                const size_t vi = ((size_t)sg * NV + py) * NV + px;
-                if (MODE == 0) {
-                    const float cr = 0.4f * T + f.amb[0] * ao[s];
-                    const float cg = 0.4f * T + f.amb[1] * ao[s];
-                    const float cb = 0.4f * T + f.amb[2] * ao[s];
-                    brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, dens[s]));  // volumeTex[int3(xy, slice)]
-                } else {
-                    scratch[vi] = make_float2(dens[s], ao[s]);
+                for (int s = 0; s < CH; ++s) {
+                    const int sg = c0 + s;
+                    const bool inShadow = sg >= shadowIndex;
+                    if (inShadow) T = 0.0f;
+                    else if (sg < f.border_index) prop = T;
+                    const size_t vi = ((size_t)sg * NV + py) * NV + px;
+                    if (MODE == 0) {
+                        const float cr = 0.4f * T + f.amb[0] * ao[s];
+                        if (GREYB) {
+                            brick32[vi] = pack_half2(cr, dens[s]);
+                        } else {
+                            const float cg = 0.4f * T + f.amb[1] * ao[s];
+                            const float cb = 0.4f * T + f.amb[2] * ao[s];
+                            brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, dens[s]));
+                        }
+                    } else {
+                        scratch[vi] = make_float2(dens[s], ao[s]);
+                    }
+                    T *= 1.0f / (1.0f + dens[s]);                                        // rcp(1 + density) :244
                 }
-                T *= 1.0f / (1.0f + dens[s]);                                            // rcp(1 + density) :244
-            }
+            };
+            if (MODE == 0 && f.grey) propagate_store(std::true_type{}); else propagate_store(std::false_type{});
         }
     }
     p_light_out[lmi] = prop;                                                             // lightPropogationTex[..] :250
@@ -589,7 +608,8 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const float* __restri
             const float cr = 0.4f * T + f.amb[0] * da.y;
             const float cg = 0.4f * T + f.amb[1] * da.y;
             const float cb = 0.4f * T + f.amb[2] * da.y;
-            brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, da.x));
+            if (f.grey) reinterpret_cast<uint32_t*>(p_bricks)[(size_t)bi * NV * NV * NV + vi] = pack_half2(cr, da.x);
+            else brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, da.x));
             T *= 1.0f / (1.0f + da.x);
         }
     }
@@ -637,14 +657,14 @@ k_fill_value(float* __restrict__ d, size_t n, float v)
 // LDS image of an R8 cube map: bytes [face][S+2][S+2], texel (ix, iy) for ix, iy in [-1, S] with clamp addressing baked in, so the
 // kernel's quad (ix, iy) .. (ix+1, iy+1), ix, iy in [-1, S-1], is four unguarded byte reads.
 __global__ void __launch_bounds__(256)
-k_build_cube_u8(const uint8_t* __restrict__ cube, int S, uint8_t* __restrict__ out, int nbytes)
+k_build_cube_u8(const uint8_t* __restrict__ cube, int S, int pitch, uint8_t* __restrict__ out, int nbytes)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nbytes) return;
-    const int S2 = S + 2, n = 6 * S2 * S2;
+    const int S2 = S + 2, n = 6 * S2 * pitch;
     uint8_t v = 0;
     if (i < n) {
-        const int ix = i % S2 - 1, iy = (i / S2) % S2 - 1, face = i / (S2 * S2);
+        const int ix = i % pitch - 1, iy = (i / pitch) % S2 - 1, face = i / (S2 * pitch);      // columns beyond S + 1 are padding
         v = cube[(size_t)face * S * S + min(max(iy, 0), S - 1) * S + min(max(ix, 0), S - 1)];
     }
     out[i] = v;
@@ -716,12 +736,13 @@ int launch_fill_value(vp_ctx* c, float* d, size_t n, float v)
     return VP_OK;
 }
 
-size_t cube_u8_bytes(int S) { return (((size_t)6 * (S + 2) * (S + 2)) + 15) & ~(size_t)15; }
+int cube_u8_pitch(int S) { return S == 128 ? VPFX_LDS_PITCH_128 : S + 2; }
+size_t cube_u8_bytes(int S) { return (((size_t)6 * (S + 2) * cube_u8_pitch(S)) + 15) & ~(size_t)15; }
 
 int launch_build_cube_u8(vp_ctx* c, const void* d_cube_r8, int S)
 {
     const int nbytes = (int)cube_u8_bytes(S);
-    hipLaunchKernelGGL(k_build_cube_u8, dim3((nbytes + 255) / 256), dim3(256), 0, c->stream, (const uint8_t*)d_cube_r8, S, (uint8_t*)c->d_cube_u8, nbytes);
+    hipLaunchKernelGGL(k_build_cube_u8, dim3((nbytes + 255) / 256), dim3(256), 0, c->stream, (const uint8_t*)d_cube_r8, S, cube_u8_pitch(S), (uint8_t*)c->d_cube_u8, nbytes);
     VP_HIP(hipGetLastError());
     return VP_OK;
 }
@@ -768,6 +789,7 @@ int launch_fill_one(vp_ctx* c, int xx, int yy, int zz)
     }
 #undef VPFX_FILL_ONE
     VP_HIP(hipGetLastError());
+    c->bricks_grey = c->fc.grey != 0;
     return VP_OK;
 }
 
@@ -793,6 +815,7 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     }
     if (rc) return rc;
     VP_HIP(hipGetLastError());
+    if (mode != 1) c->bricks_grey = c->fc.grey != 0;          // the format the bricks now hold
     VP_HIP(hipEventRecord(c->ev[evi][1], c->stream));
     c->ev_valid[evi] = true;
     return VP_OK;

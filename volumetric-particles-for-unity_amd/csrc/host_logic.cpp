@@ -101,8 +101,11 @@ void hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p)
     f.D = p->displacement_scale;
     f.one_minus_D = 1.0f - p->displacement_scale;
     f.D_over_255 = p->displacement_scale / 255.0f;
-    f.lds_pitch = c->cubeS + 2;
+    f.lds_pitch = cube_u8_pitch(c->cubeS);
     f.d_is_one = p->displacement_scale == 1.0f ? 1 : 0;
+    // grey ambient (the reference's default, scene:9021): r = g = b in every voxel -> (luminance, density) bricks; needs border >= 1
+    // (the border-less brick filters with wrap-around, which only the RGBA sampling path implements)
+    f.grey = (p->ambient[0] == p->ambient[1] && p->ambient[1] == p->ambient[2] && g.b >= 1 && c->cfg.reserved[1] != VPFX_CFG_NO_GREY_BRICKS) ? 1 : 0;
     f.init_light = p->init_light_intensity;
     for (int i = 0; i < 3; ++i) f.amb[i] = p->ambient[i];
     f.fade = p->fade_out_particles;

@@ -74,6 +74,18 @@ __device__ __forceinline__ void wait_quad(u32x4& a, u32x4& b, u32x4& c, u32x4& d
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 __device__ __forceinline__ TexelPair as_pair(const u32x4 q) { return TexelPair{q[0], q[1], q[2], q[3]}; }
+// the same for grey bricks (4 bytes per voxel: luminance | density): an x-pair of texels is 8 bytes
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void issue_load8(u32x2& q, const void* p)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_quad8(u32x2& a, u32x2& b, u32x2& c, u32x2& d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 __device__ __forceinline__ F4 lerp4(const F4& a, const F4& b, float t)
@@ -149,10 +161,15 @@ __device__ __forceinline__ RayCtx ray_setup(const RmConsts& k, int col, int row,
 // expressed in THIS metavoxel's unit-cube space through _CameraToMetavoxel (mv translation column `tr`), so
 // tEntry / tExit / tCamera are bit-identical to the per-draw values.  Returns false when the rasteriser would
 // not have produced a fragment (or the shader's own box test misses); src is premultiplied (rgb, 1 - T).
-template <int NV, bool WRAP, bool FLAGS>
+// GREY: the brick is stored as (luminance, density) fp16 pairs, 4 bytes per voxel -- the fill does that when the ambient colour is grey
+// (the reference's default, scene:9021), where r = g = b bit for bit (diffuse is the scalar 0.4 T, Fill.shader:239-241): half the bytes to
+// fetch and half the channels to filter, same image.  `brick` then points at 32-bit texels.
+template <int NV, bool WRAP, bool FLAGS, bool GREY>
 __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, const uint2* __restrict__ brick, const float4 tr,
                                          F4& src, int& nsamp)
 {
+    static_assert(!(WRAP && GREY), "grey bricks are only used with border >= 1 (the footprint never wraps)");
+    const uint32_t* __restrict__ gbrick = reinterpret_cast<const uint32_t*>(brick);
     const float ox = R.lx + tr.x, oy = R.ly + tr.y, oz = R.lz + tr.z;                     // mvRay.o :216
     // IntersectBox(mvRay, -0.5, 0.5)                                                      RM.shader:95-118
     const float tbx = R.idx * (-0.5f - ox), tby = R.idy * (-0.5f - oy), tbz = R.idz * (-0.5f - oz);
@@ -180,6 +197,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     // loads of two samples can be issued back to back before either is filtered
     struct Addr { const uint2* p; float wx, wy, wz; int ix, iy, iz; };
     struct Quad { TexelPair t00, t10, t01, t11; };    // [z][y]: texels (x0, x0+1)
+    struct QuadG { uint32_t a0, a1, b0, b1, c0, c1, d0, d1; };   // grey: [z0y0], [z0y1], [z1y0], [z1y1] x (x0, x0+1), each lum | dens
     auto address = [&](int si) -> Addr {
         const float fi = (float)si;
         const float fx = fmaf(fi, fsx, f0x), fy = fmaf(fi, fsy, f0y), fz = fmaf(fi, fsz, f0z);
@@ -190,7 +208,8 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
             // border >= 1: the 2x2x2 footprint never leaves the brick (texel coords lie in [b-0.5, nv-b-0.5]), so the
             // x-neighbours are one 16-byte load and the y / z neighbours fixed offsets from one base address.
             // (z0*NV + y0)*NV + x0 in float (exact: small integers), one conversion
-            a.p = brick + (int)fmaf(fmaf(z0, (float)NV, y0), (float)NV, x0);
+            const int idx = (int)fmaf(fmaf(z0, (float)NV, y0), (float)NV, x0);
+            a.p = GREY ? reinterpret_cast<const uint2*>(gbrick + idx) : brick + idx;
             a.ix = a.iy = a.iz = 0;
         } else {
             a.p = brick;
@@ -216,6 +235,24 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
             q.t01 = TexelPair{c0.x, c0.y, c1.x, c1.y}; q.t11 = TexelPair{d0.x, d0.y, d1.x, d1.y};
         }
         return q;
+    };
+    auto fetch_grey = [&](const Addr& a) -> QuadG {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(a.p);
+        const uint2 r0 = *reinterpret_cast<const uint2*>(p), r1 = *reinterpret_cast<const uint2*>(p + NV);
+        const uint2 r2 = *reinterpret_cast<const uint2*>(p + NV * NV), r3 = *reinterpret_cast<const uint2*>(p + NV * NV + NV);
+        return QuadG{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+    };
+    // grey: two channels (luminance in the low halves, density in the high halves), 8 v_fma_mix_f32 each
+    auto filter_grey = [&](const QuadG& q, const Addr& a) -> F4 {
+        const float ax = 1.0f - a.wx, ay = 1.0f - a.wy, az = 1.0f - a.wz;
+        const float w00 = ay * az, w10 = a.wy * az, w01 = ay * a.wz, w11 = a.wy * a.wz;         // [z][y]
+        const float w00a = w00 * ax, w00b = w00 * a.wx, w10a = w10 * ax, w10b = w10 * a.wx;
+        const float w01a = w01 * ax, w01b = w01 * a.wx, w11a = w11 * ax, w11b = w11 * a.wx;
+        const float lum = mix_fma_lo(w11b, q.d1, mix_fma_lo(w11a, q.d0, mix_fma_lo(w01b, q.c1, mix_fma_lo(w01a, q.c0,
+                          mix_fma_lo(w10b, q.b1, mix_fma_lo(w10a, q.b0, mix_fma_lo(w00b, q.a1, mix_fma_lo(w00a, q.a0, 0.f))))))));
+        const float den = mix_fma_hi(w11b, q.d1, mix_fma_hi(w11a, q.d0, mix_fma_hi(w01b, q.c1, mix_fma_hi(w01a, q.c0,
+                          mix_fma_hi(w10b, q.b1, mix_fma_hi(w10a, q.b0, mix_fma_hi(w00b, q.a1, mix_fma_hi(w00a, q.a0, 0.f))))))));
+        return F4{lum, lum, lum, den};
     };
     // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math), then y
     // and z in f32.
@@ -243,7 +280,8 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     };
     auto blend = [&](const F4& c, float density) {
         const float bf = __builtin_amdgcn_rcpf(1.0f + density);                           // :272
-        rr = fmaf(bf, rr - c.x, c.x); rg = fmaf(bf, rg - c.y, c.y); rb = fmaf(bf, rb - c.z, c.z);   // lerp(color, result, bf) :274
+        rr = fmaf(bf, rr - c.x, c.x);                                                     // lerp(color, result, bf) :274
+        if (!GREY) { rg = fmaf(bf, rg - c.y, c.y); rb = fmaf(bf, rb - c.z, c.z); }        // (grey: g and b are r, copied at the end)
         trans *= bf;                                                                      // :275
     };
     // soft particles (:267-270) only touch lattice indices below tCamera + _SoftDistance; everything farther from the camera
@@ -254,7 +292,19 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     for (; si - 1 >= tSoft; si -= 2) {
         const Addr a0 = address(si), a1 = address(si - 1);
         Quad q0, q1;
-        if (!WRAP) {
+        if (GREY) {
+            u32x2 u0, u1, u2, u3, v0, v1, v2, v3;
+            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a0.p); const uint32_t* p1 = reinterpret_cast<const uint32_t*>(a1.p);
+            const uint32_t* z0p = p0 + NV * NV; const uint32_t* z1p = p1 + NV * NV;
+            issue_load8<0>(u0, p0); issue_load8<NV * 4>(u1, p0); issue_load8<0>(u2, z0p); issue_load8<NV * 4>(u3, z0p);
+            issue_load8<0>(v0, p1); issue_load8<NV * 4>(v1, p1); issue_load8<0>(v2, z1p); issue_load8<NV * 4>(v3, z1p);
+            wait_quad8<4>(u0, u1, u2, u3);
+            const F4 c0 = filter_grey(QuadG{u0[0], u0[1], u1[0], u1[1], u2[0], u2[1], u3[0], u3[1]}, a0);
+            blend(c0, c0.w);
+            wait_quad8<0>(v0, v1, v2, v3);
+            const F4 c1 = filter_grey(QuadG{v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]}, a1);
+            blend(c1, c1.w);
+        } else if (!WRAP) {
             u32x4 u0, u1, u2, u3, v0, v1, v2, v3;
             const uint2* z0p = a0.p + NV * NV; const uint2* z1p = a1.p + NV * NV;       // the z+1 plane is beyond the 12-bit offset
             issue_load16<0>(u0, a0.p); issue_load16<NV * 8>(u1, a0.p); issue_load16<0>(u2, z0p); issue_load16<NV * 8>(u3, z0p);
@@ -277,12 +327,14 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     }
     for (; si >= tEntry; --si) {
         const Addr a = address(si);
-        const F4 c = filter(fetch(a), a);
+        F4 c;
+        if constexpr (GREY) c = filter_grey(fetch_grey(a), a); else c = filter(fetch(a), a);
         const int dc = si - tCamera;
         blend(c, dc < k.soft ? c.w * ((float)dc * k.inv_soft) : c.w);
     }
     const int ns = max(0, tExit - tEntry + 1);
     nsamp += ns;
+    if (GREY) { rg = rr; rb = rr; }
     src = F4{rr, rg, rb, 1.0f - trans};                                                   // :301
     if (FLAGS && (k.flags & VP_RM_SHOW_NUM_SAMPLES)) {                                    // debug view :283-299
         src = ns < 5 ? F4{0.f, 0.2f, 0.f, 0.5f} : ns < 10 ? F4{0.f, 0.5f, 0.f, 0.5f} : ns < 20 ? F4{0.5f, 0.5f, 0.f, 0.5f}
@@ -411,7 +463,7 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #ifndef VPFX_RM_WAVES_PARTIAL
 #define VPFX_RM_WAVES_PARTIAL 3   // partial images + flag paths (debug views of a slab): the one combination that needs > 128 VGPRs
 #endif
-template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
+template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY>
 __global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : VPFX_RM_WAVES)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
@@ -555,7 +607,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             const int bi = occ[best_cell];
             F4 src;
             const int ns0 = nsamp;
-            if (!march_mv<NV, WRAP, FLAGS>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+            const uint2* brick = GREY ? reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(bricks) + (size_t)bi * NV * NV * NV)
+                                      : bricks + (size_t)bi * NV * NV * NV;
+            if (!march_mv<NV, WRAP, FLAGS, GREY>(k, R, brick, mvtrans[bi], src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
                 src = phaseA ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
@@ -610,7 +664,7 @@ k_order_index(RmConsts k, const int* __restrict__ occ_list, const int* __restric
 // RenderMetavoxel(xx, yy, zz, orderIndex) (VPR.cs:766-794) as the reference submits it: ONE metavoxel, every pixel of the target,
 // blended into particlesRT with the blend state RenderMetavoxels set (VPR.cs:659-662 OVER / 688-691 UNDER).  The per-metavoxel
 // entry point of the C ABI (debugging, literal replays of the reference's draw loop); the frame path is k_raymarch.
-template <int NV, bool WRAP>
+template <int NV, bool WRAP, bool GREY>
 __global__ void __launch_bounds__(256)
 k_raymarch_one(RmConsts k, const uint2* __restrict__ brick, float4 tr, const float* __restrict__ scene_depth, float4* __restrict__ img,
                int blend_over, int order_index, unsigned long long* __restrict__ samples)
@@ -620,7 +674,7 @@ k_raymarch_one(RmConsts k, const uint2* __restrict__ brick, float4 tr, const flo
     const RayCtx R = ray_setup(k, col, row, scene_depth);
     F4 src;
     int nsamp = 0;
-    if (!march_mv<NV, WRAP, true>(k, R, brick, tr, src, nsamp)) return;       // no fragment: the ROP is not touched
+    if (!march_mv<NV, WRAP, true, GREY>(k, R, brick, tr, src, nsamp)) return;  // no fragment: the ROP is not touched
     if (k.flags & VP_RM_SHOW_BLEND_FUNC) src = blend_over ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
     if (k.flags & VP_RM_SHOW_DRAW_ORDER) src = draw_order_color(order_index, k.num_covered);
     const size_t pi = (size_t)row * k.W + col;
@@ -669,7 +723,7 @@ k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, si
     scene[i] = d;
 }
 
-template <int NV, bool PARTIAL, bool WRAP, bool FLAGS>
+template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY = false>
 void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
 {
     const int nsuper = rm_num_super_tiles(k.W, k.H);
@@ -683,7 +737,7 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
     }
 #endif
     const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
-    hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
+    hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS, GREY>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
                        c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out);
 }
 
@@ -692,6 +746,15 @@ void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, i
 {
     const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
     const int sel = (d_under ? 4 : 0) | (wrap ? 2 : 0) | (k.flags ? 1 : 0);
+    if (c->bricks_grey) {                  // (luminance, density) bricks: only ever filled with border >= 1
+        switch (sel & 5) {
+        case 0: launch_rm_variant<NV, false, false, false, true>(c, k, d_over, d_under, early_out); break;
+        case 1: launch_rm_variant<NV, false, false, true, true>(c, k, d_over, d_under, early_out); break;
+        case 4: launch_rm_variant<NV, true, false, false, true>(c, k, d_over, d_under, early_out); break;
+        default: launch_rm_variant<NV, true, false, true, true>(c, k, d_over, d_under, early_out); break;
+        }
+        return;
+    }
     switch (sel) {
     case 0: launch_rm_variant<NV, false, false, false>(c, k, d_over, d_under, early_out); break;
     case 1: launch_rm_variant<NV, false, false, true>(c, k, d_over, d_under, early_out); break;
@@ -757,12 +820,15 @@ int launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_
     const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
     const bool wrap = c->g.b < 1;
     const size_t nv3 = (size_t)k.nv * k.nv * k.nv;
-    const uint2* brick = c->d_bricks + (size_t)bi * nv3;
+    const uint2* brick = c->bricks_grey ? reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(c->d_bricks) + (size_t)bi * nv3)
+                                        : c->d_bricks + (size_t)bi * nv3;
 #define VPFX_RM_ONE(NV)                                                                                                        \
     do {                                                                                                                        \
-        if (wrap) hipLaunchKernelGGL((k_raymarch_one<NV, true>), grid, block, 0, c->stream, k, brick, trv, c->d_scene_depth,    \
+        if (c->bricks_grey) hipLaunchKernelGGL((k_raymarch_one<NV, false, true>), grid, block, 0, c->stream, k, brick, trv,      \
+                                     c->d_scene_depth, (float4*)d_img, blend_over, order_index, c->d_samples);                  \
+        else if (wrap) hipLaunchKernelGGL((k_raymarch_one<NV, true, false>), grid, block, 0, c->stream, k, brick, trv, c->d_scene_depth,    \
                                      (float4*)d_img, blend_over, order_index, c->d_samples);                                    \
-        else      hipLaunchKernelGGL((k_raymarch_one<NV, false>), grid, block, 0, c->stream, k, brick, trv, c->d_scene_depth,   \
+        else      hipLaunchKernelGGL((k_raymarch_one<NV, false, false>), grid, block, 0, c->stream, k, brick, trv, c->d_scene_depth,   \
                                      (float4*)d_img, blend_over, order_index, c->d_samples);                                    \
     } while (0)
     switch (k.nv) {

@@ -13,6 +13,8 @@
 
 // vp_config.reserved[0]: test / measurement switch -- 1 keeps an R8 cube map on the global f32 footprint table (A/B against the LDS path)
 #define VPFX_CFG_NO_LDS_CUBEMAP 1
+// vp_config.reserved[1]: 1 keeps RGBA16F bricks when the ambient colour is grey (A/B against the luminance|density format)
+#define VPFX_CFG_NO_GREY_BRICKS 1
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel-constant PODs (passed by value as kernel arguments -> SGPRs / kernarg segment)
@@ -46,8 +48,9 @@ struct FillConsts {
     float half_s, half_s_m05;     // S/2, S/2 - 0.5
     int   border_index;           // nv - clamp(b, 0, nv-2)                                Fill.shader:229
     float D_over_255;             // displacement scale for byte texels (R8 cube map in LDS): net = (D/255) * bilinear(bytes) + (1 - D)
-    int   lds_pitch;              // S + 2: row pitch of the padded byte table
+    int   lds_pitch;              // row pitch of the padded byte table (cube_u8_pitch: S + 2 rounded up for bank spread)
     int   d_is_one;               // displacement scale == 1 exactly (net displacement can be 0: see cube_shade)
+    int   grey;                   // ambient r == g == b: bricks stored as (luminance, density), 4 bytes per voxel
 };
 
 struct RmConsts {
@@ -115,7 +118,8 @@ struct vp_ctx {
     DevMeta h_meta{};
 
     // fill
-    uint2* d_bricks = nullptr;    // [brick_cap][nv^3] RGBA16F
+    uint2* d_bricks = nullptr;    // [brick_cap][nv^3] RGBA16F (or, bricks_grey: the first half of it as [.][nv^3] luminance|density fp16 pairs)
+    bool bricks_grey = false;     // format of the bricks as last filled
     size_t brick_cap = 0;
     float2* d_dens_ao = nullptr;  // split-fill scratch [brick_cap][nv^3]
     size_t dens_cap = 0;
@@ -194,7 +198,8 @@ int  launch_z_histogram(vp_ctx* c, int* d_hist);
 // fill.hip
 int  launch_build_cubequads(vp_ctx* c, const void* d_cube, int format, int S, int* d_bad);
 int  launch_build_cube_u8(vp_ctx* c, const void* d_cube_r8, int S);                    // padded byte table for the LDS path
-size_t cube_u8_bytes(int S);                                                          // 6 (S+2)^2 rounded up to 16
+int  cube_u8_pitch(int S);                                                            // row pitch of the padded byte table
+size_t cube_u8_bytes(int S);                                                          // 6 (S+2) rows of that pitch, rounded up to 16
 int  launch_fill_one(vp_ctx* c, int xx, int yy, int zz);
 int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v);                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
