@@ -94,9 +94,9 @@ def one_case(seed):
             worst_abs = max(worst_abs, float(np.abs(fa.astype(np.float32) - fb.astype(np.float32))[du > 1].max()))
     # EXACT math: bit-identical.  Default math (v_rcp_f32 in the cube addressing and the smoothstep): <= 1 fp16 ulp -- except that
     # with a white-noise cube map and displacement scale near 1 (net displacement near 0) the smoothstep's t = 10/3 - (40/3) d2/net
-    # amplifies the reciprocal's last bit, which shows in near-zero densities (1e-4, a dozen fp16 ulp = 1e-6 absolute); bounded
+    # amplifies the reciprocal's last bit, which shows in near-zero densities (1e-4, a dozen fp16 ulp = 1e-6 .. 3e-5 absolute); bounded
     # absolutely there.  Both table paths (LDS bytes, global floats) deviate identically.
-    assert worst <= (0 if exact else 1) or (not exact and worst_abs <= 2e-5), f"brick ulp {worst} abs {worst_abs:.2e} (exact={exact})"
+    assert worst <= (0 if exact else 1) or (not exact and worst_abs <= 1e-4), f"brick ulp {worst} abs {worst_abs:.2e} (exact={exact})"
     np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5 if exact else 5e-5, atol=1e-9)
     cam, rp = sc.camera(), sc.raymarch_params()
     io, ig, ie = o.raymarch(cam, rp), g.raymarch(cam, rp), ge.raymarch(cam, rp)
