@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
 LDS = WHICH == "fill_lds"
 SRC = WHICH if WHICH.endswith(".hip") else os.path.join(CSRC, ("fill" if LDS else WHICH) + ".hip")
 KERNEL = "k_raymarch" if "raymarch" in os.path.basename(SRC) else ("k_fill_lds" if LDS else "k_fill")
-LOAD_RE = (r"global_load_dwordx4\s+(v\[\d+:\d+\]),\s*v\[\d+:\d+\],\s*off" if KERNEL == "k_raymarch"
+LOAD_RE = (r"global_load_dwordx[24]\s+(v\[\d+:\d+\]),\s*v\[\d+:\d+\],\s*off" if KERNEL == "k_raymarch"
            else r"ds_read_u8\s+(v\d+),\s*v\d+" if LDS
            else r"global_load_dwordx4\s+(v\[\d+:\d+\]),\s*v\d+,\s*s\[\d+:\d+\]")
 COUNTER = "lgkmcnt" if LDS else "vmcnt"
