@@ -13,6 +13,6 @@ for set in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY
   i=$((i+1))
   timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p$i -- $CMD > $OUT/p$i.log 2>&1
 done
-python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $OUT/p*/p*_results.db 2>&1 | grep -E "k_fill<32|k_raymarch<32" | grep -vE "^\S+\s+\S+\s+[0-9]+\s+[0-9.]+\s+[0-9.]+\s+[0-9.]+$" > $OUT/summary.txt
+python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $OUT/p*/p*_results.db 2>&1 | grep -E "k_fill|k_raymarch<32" | grep -vE "^\S+\s+\S+\s+[0-9]+\s+[0-9.]+\s+[0-9.]+\s+[0-9.]+$" > $OUT/summary.txt
 rm -rf $OUT/*/*.db
 cat $OUT/summary.txt | cut -c1-110
