@@ -9,6 +9,7 @@ for cfg in C1 C2; do
 done
 timeout 600 python bench.py --cubemap f32 --steps 200 --warmup 5 --no-cpu-baseline 2> /dev/null | tail -1 > gpurun_out/r2/bench_C3_f32.json
 timeout 600 python bench.py --no-lds-cubemap --steps 200 --warmup 5 --no-cpu-baseline 2> /dev/null | tail -1 > gpurun_out/r2/bench_C3_r8_global_table.json
+timeout 600 python bench.py --no-grey --steps 200 --warmup 5 --no-cpu-baseline 2> /dev/null | tail -1 > gpurun_out/r2/bench_C3_rgba_bricks.json
 timeout 600 python bench.py --steps 200 --warmup 5 2> /dev/null | tail -1 > gpurun_out/r2/bench_C3.json
 timeout 900 python scripts/scaling_model.py C3 r8 > gpurun_out/r2/scaling_model.log 2>&1
 timeout 900 python scripts/run_c5.py > gpurun_out/r2/c5.log 2>&1
