@@ -491,8 +491,12 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     if (ttx >= tgx || tty >= tgy) return;
     // wave = 8 x 8 px.  (16 x 4 px touches fewer brick rows per load -- the L1 tag rate is what binds this kernel -- but loses traversal
     // coherence: 1.50 ms against 1.47; 4 x 16 px: 1.57.)
-    const int col = ttx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int row = tty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    // lanes row-major in the tile: the L1 serves a wave-load one lane quad per cycle when the quad's addresses share a 128-B line
+    // (scripts/probes/l1_gather_probe.hip), and four pixels in a screen row share a brick row more often than a 2 x 2 px quad does
+    // (Z-order lanes: 1.62 ms against 1.46).
+    const int lx = lane & 7, ly = lane >> 3;
+    const int col = ttx * 16 + (wave & 1) * 8 + lx;
+    const int row = tty * 16 + (wave >> 1) * 8 + ly;
     if (col >= k.W || row >= k.H) return;
 
     const RayCtx R = ray_setup(k, col, row, scene_depth);
