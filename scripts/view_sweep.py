@@ -1,0 +1,40 @@
+"""Ray-march kernel time of the benchmark scene (C3) from several view directions / rolls: the brick rows run along the grid's x axis, so the
+L1 cost of the trilinear footprint loads depends on how screen rows map onto the grid.  GPU only:  gpurun -- python scripts/view_sweep.py"""
+import os, sys, importlib
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("volumetric-particles-for-unity_amd")
+from importlib import import_module
+scene = import_module("volumetric-particles-for-unity_amd.scene")
+engine = import_module("volumetric-particles-for-unity_amd.engine")
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+    sc = scene.make_scene(cfg, cubemap="r8")
+    eng = engine.Engine(sc.config(device=0))
+    eng.set_frame(sc.light_to_world, sc.grid_center)
+    eng.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    eng.fill(sc.fill_params())
+    D = 0.8 * sc.N[0] * sc.mv_scale
+    views = [("benchmark camera", None, (0, 1, 0)),
+             ("same position, rolled 90 deg", "bench", (1, 0, 0)),
+             ("from +x", (D, 0.05 * D, 0.125 * D), (0, 1, 0)),
+             ("from +x, rolled 90 deg", (D, 0.05 * D, 0.125 * D), (0, 0, 1)),
+             ("from +y (down the light axis?)", (0.125 * D, D, 0.05 * D), (0, 0, 1)),
+             ("from -z -x diagonal", (-0.7 * D, 0.05 * D, -0.7 * D), (0, 1, 0))]
+    bench_pos = tuple(float(x) for x in sc.cam_pos)
+    for name, pos, up in views:
+        pos = bench_pos if pos in (None, "bench") else pos
+        sc.cam_to_world, sc.world_to_cam = scene.look_at_camera(pos, (0.0, 0.0, 0.0), up)
+        sc.cam_pos = np.asarray(pos, dtype=np.float32)
+        ts = []
+        img = np.empty((sc.height, sc.width, 4), dtype=np.float32)
+        for _ in range(6):
+            eng.raymarch(sc.camera(), sc.raymarch_params(), out=img)
+            st = eng.stats()
+            ts.append(eng.last_kernel_ms(2))
+        print(f"{name:34s}: k_raymarch {np.median(ts[1:]):.3f} ms, {st['samples'] / 1e6:.0f} M samples, {st['samples'] / np.median(ts[1:]) / 1e6:.1f} Gsamples/s", flush=True)
+
+if __name__ == "__main__":
+    main()
