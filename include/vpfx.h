@@ -141,6 +141,9 @@ typedef struct vp_obb {
     float half_extent[3];
 } vp_obb;
 
+#define VP_BRICKS_RGBA16F    0
+#define VP_BRICKS_GREY_ZPAIR 1
+
 typedef struct vp_stats {
     int64_t particles;            /* particles uploaded                                           */
     int64_t occupied_mv;          /* numMetavoxelsCovered (VPR.cs:515), within the owned slab     */
@@ -150,9 +153,11 @@ typedef struct vp_stats {
     int64_t brick_bytes;          /* resident brick pool bytes                                    */
     int64_t max_pairs_per_mv;
     int64_t bricks_sampled;       /* bricks that contributed >= 1 sample to the last vp_raymarch* call */
-    int64_t brick_bytes_per_voxel;/* 8 = RGBA16F; 4 = (luminance, density) fp16 pairs: the storage the library picks when the
-                                     ambient colour is grey (r = g = b in every voxel); vp_read_brick always returns RGBA16F */
-    int64_t reserved[3];
+    int64_t brick_bytes_per_voxel;/* 8 (both storage formats below)                               */
+    int64_t brick_format;         /* VP_BRICKS_RGBA16F, or VP_BRICKS_GREY_ZPAIR: (luminance, density) fp16 pairs of the voxel and of its
+                                     z + 1 neighbour -- the storage the library picks when the ambient colour is grey (r = g = b in
+                                     every voxel) and volume_border >= 1; vp_read_brick always returns RGBA16F */
+    int64_t reserved[2];
 } vp_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

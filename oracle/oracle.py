@@ -191,7 +191,7 @@ def _stats_struct():
         _fields_ = [("particles", C.c_int64), ("occupied_mv", C.c_int64), ("pairs", C.c_int64),
                     ("voxels_filled", C.c_int64), ("samples", C.c_int64), ("brick_bytes", C.c_int64),
                     ("max_pairs_per_mv", C.c_int64), ("bricks_sampled", C.c_int64), ("brick_bytes_per_voxel", C.c_int64),
-                    ("reserved", C.c_int64 * 3)]
+                    ("brick_format", C.c_int64), ("reserved", C.c_int64 * 2)]
     return vp_stats
 
 

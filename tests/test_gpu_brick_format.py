@@ -1,6 +1,6 @@
 """GPU: the two brick storage formats.  With a grey ambient colour (the reference's default, scene:9021) every voxel has r = g = b
-bit for bit (diffuse is the scalar 0.4 T, Fill.shader:239-241), and the library stores (luminance, density) fp16 pairs -- 4 bytes per
-voxel -- instead of RGBA16F; a coloured ambient keeps RGBA16F.  Both must be the oracle's bricks and image, and on a grey scene both
+bit for bit (diffuse is the scalar 0.4 T, Fill.shader:239-241), and the library stores (luminance, density) fp16 pairs of the voxel and of
+its z + 1 neighbour instead of RGBA16F (two footprint loads per ray-march sample instead of four); a coloured ambient keeps RGBA16F.  Both must be the oracle's bricks and image, and on a grey scene both
 formats must give the SAME bricks (as read through vp_read_brick) and the same image bit for bit."""
 import numpy as np
 import pytest
@@ -35,7 +35,7 @@ def oracle(sc):
 def test_grey_and_rgba_storage_are_the_same_bricks_and_image(dims, cubemap):
     sc = S.make_scene("g", dims=dims, cubemap=cubemap)
     a, b = run(sc, early_out=False), run(sc, rgba_only=True, early_out=False)
-    assert a.stats()["brick_bytes_per_voxel"] == 4 and b.stats()["brick_bytes_per_voxel"] == 8
+    assert a.stats()["brick_format"] == abi.VP_BRICKS_GREY_ZPAIR and b.stats()["brick_format"] == abi.VP_BRICKS_RGBA16F
     cnt = a.bin_counts()
     for zz, yy, xx in zip(*np.nonzero(cnt)):
         assert np.array_equal(a.read_brick(xx, yy, zz).view(np.uint16), b.read_brick(xx, yy, zz).view(np.uint16)), (xx, yy, zz)
@@ -59,7 +59,7 @@ def test_coloured_ambient_keeps_rgba_bricks_and_matches_the_oracle(ambient, exac
     sc = S.make_scene("c", dims=(6, 16, 300, 96, 64))
     sc.ambient = ambient
     g = run(sc, exact=exact, early_out=False)
-    assert g.stats()["brick_bytes_per_voxel"] == 8
+    assert g.stats()["brick_format"] == abi.VP_BRICKS_RGBA16F
     o = oracle(sc)
     cnt = o.bin_counts()
     for zz, yy, xx in zip(*np.nonzero(cnt)):
@@ -73,7 +73,7 @@ def test_coloured_ambient_keeps_rgba_bricks_and_matches_the_oracle(ambient, exac
 def test_border_zero_keeps_rgba_bricks():
     sc = S.make_scene("b0", dims=(4, 16, 150, 96, 64), border=0)   # wrap-around filtering: RGBA sampling path only
     g = run(sc)
-    assert g.stats()["brick_bytes_per_voxel"] == 8
+    assert g.stats()["brick_format"] == abi.VP_BRICKS_RGBA16F
     o = oracle(sc)
     assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
 
@@ -81,14 +81,14 @@ def test_border_zero_keeps_rgba_bricks():
 def test_format_follows_the_ambient_colour_from_fill_to_fill():
     sc = S.make_scene("T0")
     g = run(sc)
-    assert g.stats()["brick_bytes_per_voxel"] == 4
+    assert g.stats()["brick_format"] == abi.VP_BRICKS_GREY_ZPAIR
     sc.ambient = (0.3, 0.2, 0.1)
     g.fill(sc.fill_params())
-    assert g.stats()["brick_bytes_per_voxel"] == 8
+    assert g.stats()["brick_format"] == abi.VP_BRICKS_RGBA16F
     o = oracle(sc)
     assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
     sc.ambient = (0.2, 0.2, 0.2)
     g.fill(sc.fill_params())
-    assert g.stats()["brick_bytes_per_voxel"] == 4
+    assert g.stats()["brick_format"] == abi.VP_BRICKS_GREY_ZPAIR
     o = oracle(sc)
     assert np.abs(g.raymarch(sc.camera(), sc.raymarch_params()) - o.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3

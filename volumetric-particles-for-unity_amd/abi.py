@@ -18,6 +18,7 @@ VP_RM_SHOW_NUM_SAMPLES = 2
 VP_RM_SHOW_BLEND_FUNC = 4
 VP_RM_SHOW_DRAW_ORDER = 8
 
+VP_BRICKS_RGBA16F, VP_BRICKS_GREY_ZPAIR = 0, 1
 VP_CUBEMAP_F32 = 0
 VP_CUBEMAP_R8 = 1
 
@@ -133,7 +134,8 @@ class vp_stats(C.Structure):
         ("max_pairs_per_mv", C.c_int64),
         ("bricks_sampled", C.c_int64),
         ("brick_bytes_per_voxel", C.c_int64),
-        ("reserved", C.c_int64 * 3),
+        ("brick_format", C.c_int64),
+        ("reserved", C.c_int64 * 2),
     ]
 
 

@@ -696,12 +696,15 @@ VP_EXPORT int vp_read_brick(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, uint1
     if (bi < 0) return vp_fail(c, VP_ERR_STATE, "metavoxel (%d,%d,%d) is empty / not owned: no brick", xx, yy, zz);
     if (c->bricks_grey) {
         // (luminance, density) storage: expand to the reference's RGBA16F texel (r = g = b = luminance, a = density)
-        const size_t n = nv3(c);
-        uint32_t* tmp = (uint32_t*)malloc(n * sizeof(uint32_t));
+        // an entry is texel(z), texel(z + 1): the first word is this voxel's
+        const size_t n = nv3(c), words = 2;
+        uint32_t* tmp = (uint32_t*)malloc(n * words * sizeof(uint32_t));
         if (!tmp) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
-        hipError_t e = hipMemcpy(tmp, reinterpret_cast<const uint32_t*>(c->d_bricks) + (size_t)bi * n, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(tmp, reinterpret_cast<const uint32_t*>(c->d_bricks) + (size_t)bi * n * words, n * words * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost);
         for (size_t i = 0; i < n && e == hipSuccess; ++i) {
-            const uint16_t lum = (uint16_t)(tmp[i] & 0xffffu), den = (uint16_t)(tmp[i] >> 16);
+            const uint32_t t = tmp[i * words];
+            const uint16_t lum = (uint16_t)(t & 0xffffu), den = (uint16_t)(t >> 16);
             half_rgba[4 * i] = lum; half_rgba[4 * i + 1] = lum; half_rgba[4 * i + 2] = lum; half_rgba[4 * i + 3] = den;
         }
         free(tmp);
@@ -737,7 +740,8 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
         st->voxels_filled = (int64_t)c->h_meta.occupied * (int64_t)nv3(c);
     }
     st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));      // pool as allocated (grey bricks use the first half of it)
-    st->brick_bytes_per_voxel = c->bricks_grey ? 4 : 8;                                // bytes per voxel of the bricks as last filled
+    st->brick_bytes_per_voxel = 8;
+    st->brick_format = c->bricks_grey ? VP_BRICKS_GREY_ZPAIR : VP_BRICKS_RGBA16F;     // storage of the bricks as last filled
     VP_HIP(hipStreamSynchronize(c->stream));
     unsigned long long s = 0;
     VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));

@@ -301,6 +301,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
         uint2* brick = p_bricks + (size_t)bi * NV * NV * NV;
         float2* scratch = p_dens_ao + (size_t)bi * NV * NV * NV;
 
+        uint32_t prev_texel = 0;                          // grey z-pair bricks: the previous slice's texel of this column
 #pragma unroll 1
         for (int c0 = 0; c0 < NV; c0 += CH) {
 #if VPFX_FILL_LDS_TILE
@@ -475,7 +476,6 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             // The format is wave-uniform: the branch is taken once per chunk, outside the 32 unrolled slices.
             auto propagate_store = [&](auto grey_tag) {
                 constexpr bool GREYB = decltype(grey_tag)::value;
-                uint32_t* brick32 = reinterpret_cast<uint32_t*>(p_bricks) + (size_t)bi * NV * NV * NV;
 #pragma unroll
                 for (int s = 0; s < CH; ++s) {
                     const int sg = c0 + s;
@@ -486,7 +486,11 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     if (MODE == 0) {
                         const float cr = 0.4f * T + f.amb[0] * ao[s];
                         if (GREYB) {
-                            brick32[vi] = pack_half2(cr, dens[s]);
+                            // entry(z) = texel(z), texel(z + 1): stored one slice late, when the slice behind it is known
+                            const uint32_t cur = pack_half2(cr, dens[s]);
+                            if (sg > 0) brick[vi - (size_t)NV * NV] = make_uint2(prev_texel, cur);
+                            if (sg == NV - 1) brick[vi] = make_uint2(cur, cur);          // (the last slice is never a footprint's z0)
+                            prev_texel = cur;
                         } else {
                             const float cg = 0.4f * T + f.amb[1] * ao[s];
                             const float cb = 0.4f * T + f.amb[2] * ao[s];
@@ -598,6 +602,7 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const float* __restri
         prop = T;
         uint2* brick = p_bricks + (size_t)bi * NV * NV * NV;
         const float2* scratch = p_dens_ao + (size_t)bi * NV * NV * NV;
+        uint32_t prev_texel = 0;
 #pragma unroll 8
         for (int sg = 0; sg < NV; ++sg) {
             const size_t vi = ((size_t)sg * NV + py) * NV + px;
@@ -608,8 +613,12 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const float* __restri
             const float cr = 0.4f * T + f.amb[0] * da.y;
             const float cg = 0.4f * T + f.amb[1] * da.y;
             const float cb = 0.4f * T + f.amb[2] * da.y;
-            if (f.grey) reinterpret_cast<uint32_t*>(p_bricks)[(size_t)bi * NV * NV * NV + vi] = pack_half2(cr, da.x);
-            else brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, da.x));
+            if (f.grey) {
+                const uint32_t cur = pack_half2(cr, da.x);
+                if (sg > 0) brick[vi - (size_t)NV * NV] = make_uint2(prev_texel, cur);
+                if (sg == NV - 1) brick[vi] = make_uint2(cur, cur);
+                prev_texel = cur;
+            } else brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, da.x));
             T *= 1.0f / (1.0f + da.x);
         }
     }

@@ -76,20 +76,12 @@ __device__ __forceinline__ void wait_quad(u32x4& a, u32x4& b, u32x4& c, u32x4& d
 {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
-__device__ __forceinline__ TexelPair as_pair(const u32x4 q) { return TexelPair{q[0], q[1], q[2], q[3]}; }
-// the same for grey bricks (4 bytes per voxel: luminance | density): an x-pair of texels is 8 bytes
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-template <int OFF>
-__device__ __forceinline__ void issue_load8(u32x2& q, const void* p)
-{
-    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(q) : "v"(p), "n"(OFF) : "memory");
-}
 template <int N>
-__device__ __forceinline__ void wait_quad8(u32x2& a, u32x2& b, u32x2& c, u32x2& d)
+__device__ __forceinline__ void wait_pair(u32x4& a, u32x4& b)
 {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
-
+__device__ __forceinline__ TexelPair as_pair(const u32x4 q) { return TexelPair{q[0], q[1], q[2], q[3]}; }
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 __device__ __forceinline__ F4 lerp4(const F4& a, const F4& b, float t)
 {
@@ -164,15 +156,16 @@ __device__ __forceinline__ RayCtx ray_setup(const RmConsts& k, int col, int row,
 // expressed in THIS metavoxel's unit-cube space through _CameraToMetavoxel (mv translation column `tr`), so
 // tEntry / tExit / tCamera are bit-identical to the per-draw values.  Returns false when the rasteriser would
 // not have produced a fragment (or the shader's own box test misses); src is premultiplied (rgb, 1 - T).
-// GREY: the brick is stored as (luminance, density) fp16 pairs, 4 bytes per voxel -- the fill does that when the ambient colour is grey
-// (the reference's default, scene:9021), where r = g = b bit for bit (diffuse is the scalar 0.4 T, Fill.shader:239-241): half the bytes to
-// fetch and half the channels to filter, same image.  `brick` then points at 32-bit texels.
+// GREY: the brick holds (luminance, density) fp16 pairs -- the fill stores that when the ambient colour is grey (the reference's default,
+// scene:9021), where r = g = b bit for bit (diffuse is the scalar 0.4 T, Fill.shader:239-241) -- as Z-PAIR entries: entry (x, y, z) =
+// texel(x, y, z), texel(x, y, z + 1), 8 bytes.  One 16-byte load at (x0, y, z0) then fetches the x-pair of BOTH z planes of a trilinear
+// footprint: two loads per sample instead of four (the kernel is bound by the L1's rate of wave-loads), and half the
+// channels to filter.  Same image bit for bit as RGBA16F bricks.
 template <int NV, bool WRAP, bool FLAGS, bool GREY>
 __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, const uint2* __restrict__ brick, const float4 tr,
                                          F4& src, int& nsamp)
 {
     static_assert(!(WRAP && GREY), "grey bricks are only used with border >= 1 (the footprint never wraps)");
-    const uint32_t* __restrict__ gbrick = reinterpret_cast<const uint32_t*>(brick);
     const float ox = R.lx + tr.x, oy = R.ly + tr.y, oz = R.lz + tr.z;                     // mvRay.o :216
     // IntersectBox(mvRay, -0.5, 0.5)                                                      RM.shader:95-118
     const float tbx = R.idx * (-0.5f - ox), tby = R.idy * (-0.5f - oy), tbz = R.idz * (-0.5f - oz);
@@ -212,7 +205,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
             // x-neighbours are one 16-byte load and the y / z neighbours fixed offsets from one base address.
             // (z0*NV + y0)*NV + x0 in float (exact: small integers), one conversion
             const int idx = (int)fmaf(fmaf(z0, (float)NV, y0), (float)NV, x0);
-            a.p = GREY ? reinterpret_cast<const uint2*>(gbrick + idx) : brick + idx;
+            a.p = brick + idx;                       // grey z-pair entries are 8 bytes like RGBA16F texels
             a.ix = a.iy = a.iz = 0;
         } else {
             a.p = brick;
@@ -240,10 +233,9 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
         return q;
     };
     auto fetch_grey = [&](const Addr& a) -> QuadG {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(a.p);
-        const uint2 r0 = *reinterpret_cast<const uint2*>(p), r1 = *reinterpret_cast<const uint2*>(p + NV);
-        const uint2 r2 = *reinterpret_cast<const uint2*>(p + NV * NV), r3 = *reinterpret_cast<const uint2*>(p + NV * NV + NV);
-        return QuadG{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+        // entry (x, y, z) = texel(z), texel(z + 1): 16 bytes at (x0, y, z0) = [x0 z0, x0 z1, x1 z0, x1 z1]
+        const TexelPair r0 = *reinterpret_cast<const TexelPair*>(a.p), r1 = *reinterpret_cast<const TexelPair*>(a.p + NV);
+        return QuadG{r0.rg0, r0.rg1, r1.rg0, r1.rg1, r0.ba0, r0.ba1, r1.ba0, r1.ba1};
     };
     // grey: two channels (luminance in the low halves, density in the high halves), 8 v_fma_mix_f32 each
     auto filter_grey = [&](const QuadG& q, const Addr& a) -> F4 {
@@ -294,20 +286,20 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     int si = tExit;
     // (Measured and dropped: issuing the next two samples' eight loads before filtering the current two -- two register sets, 8-16 loads
     // in flight per wave -- 1.49 vs 1.48 ms: loads in flight per wave are not what limits the kernel.)
+    // (Grey bricks, measured: four samples per iteration -- 8 loads in flight -- 1.02 ms at 4 waves/SIMD against 1.09 for two, but the
+    // two-sample loop fits 5 waves/SIMD: 1.00 ms.)
     for (; si - 1 >= tSoft; si -= 2) {
         const Addr a0 = address(si), a1 = address(si - 1);
         Quad q0, q1;
         if (GREY) {
-            u32x2 u0, u1, u2, u3, v0, v1, v2, v3;
-            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(a0.p); const uint32_t* p1 = reinterpret_cast<const uint32_t*>(a1.p);
-            const uint32_t* z0p = p0 + NV * NV; const uint32_t* z1p = p1 + NV * NV;
-            issue_load8<0>(u0, p0); issue_load8<NV * 4>(u1, p0); issue_load8<0>(u2, z0p); issue_load8<NV * 4>(u3, z0p);
-            issue_load8<0>(v0, p1); issue_load8<NV * 4>(v1, p1); issue_load8<0>(v2, z1p); issue_load8<NV * 4>(v3, z1p);
-            wait_quad8<4>(u0, u1, u2, u3);
-            const F4 c0 = filter_grey(QuadG{u0[0], u0[1], u1[0], u1[1], u2[0], u2[1], u3[0], u3[1]}, a0);
+            u32x4 u0, u1, v0, v1;
+            issue_load16<0>(u0, a0.p); issue_load16<NV * 8>(u1, a0.p);
+            issue_load16<0>(v0, a1.p); issue_load16<NV * 8>(v1, a1.p);
+            wait_pair<2>(u0, u1);
+            const F4 c0 = filter_grey(QuadG{u0[0], u0[2], u1[0], u1[2], u0[1], u0[3], u1[1], u1[3]}, a0);
             blend(c0, c0.w);
-            wait_quad8<0>(v0, v1, v2, v3);
-            const F4 c1 = filter_grey(QuadG{v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]}, a1);
+            wait_pair<0>(v0, v1);
+            const F4 c1 = filter_grey(QuadG{v0[0], v0[2], v1[0], v1[2], v0[1], v0[3], v1[1], v1[3]}, a1);
             blend(c1, c1.w);
         } else if (!WRAP) {
             u32x4 u0, u1, u2, u3, v0, v1, v2, v3;
@@ -468,8 +460,11 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #ifndef VPFX_RM_WAVES_PARTIAL
 #define VPFX_RM_WAVES_PARTIAL 3   // partial images + flag paths (debug views of a slab): the one combination that needs > 128 VGPRs
 #endif
+#ifndef VPFX_RM_WAVES_GREY
+#define VPFX_RM_WAVES_GREY 5      // the plain grey-brick kernel needs 99 VGPRs: 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3)
+#endif
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY>
-__global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : VPFX_RM_WAVES)
+__global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : (GREY && !PARTIAL && !FLAGS) ? VPFX_RM_WAVES_GREY : VPFX_RM_WAVES)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
@@ -618,8 +613,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             const int bi = occ[best_cell];
             F4 src;
             const int ns0 = nsamp;
-            const uint2* brick = GREY ? reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(bricks) + (size_t)bi * NV * NV * NV)
-                                      : bricks + (size_t)bi * NV * NV * NV;
+            const uint2* brick = bricks + (size_t)bi * NV * NV * NV;
             if (!march_mv<NV, WRAP, FLAGS, GREY>(k, R, brick, mvtrans[bi], src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
@@ -831,8 +825,7 @@ int launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_
     const dim3 grid((k.W + 15) / 16, (k.H + 15) / 16), block(256);
     const bool wrap = c->g.b < 1;
     const size_t nv3 = (size_t)k.nv * k.nv * k.nv;
-    const uint2* brick = c->bricks_grey ? reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(c->d_bricks) + (size_t)bi * nv3)
-                                        : c->d_bricks + (size_t)bi * nv3;
+    const uint2* brick = c->d_bricks + (size_t)bi * nv3;
 #define VPFX_RM_ONE(NV)                                                                                                        \
     do {                                                                                                                        \
         if (c->bricks_grey) hipLaunchKernelGGL((k_raymarch_one<NV, false, true>), grid, block, 0, c->stream, k, brick, trv,      \
