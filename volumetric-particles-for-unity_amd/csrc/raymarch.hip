@@ -34,19 +34,9 @@ __device__ __forceinline__ F4 unpack_texel(uint2 u)
 // A texel pair (x0, x0+1) of one brick row: 16 bytes = {r0|g0, b0|a0, r1|g1, b1|a1} as packed halves.
 struct __attribute__((aligned(8))) TexelPair { uint32_t rg0, ba0, rg1, ba1; };
 
-// a + w (b - a) with a, b fp16 (low or high half of a dword) and f32 arithmetic, as two v_fma_mix_f32: the mixed-
-// precision FMA reads the packed halves directly, so no v_cvt_f32_f16 / unpacking is spent on the 32 texel values.
-//   tmp = -w * a + a ;  d = w * b + tmp
-#define VPFX_MIX_LERP(HI)                                                                                          \
-    asm("v_fma_mix_f32 %0, -%1, %2, %2 op_sel:[0," #HI "," #HI "] op_sel_hi:[0,1,1]" : "=v"(tmp) : "v"(w), "v"(a)); \
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0," #HI ",0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(b), "v"(tmp));
-__device__ __forceinline__ float mix_lerp_lo(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(0) return d; }
-__device__ __forceinline__ float mix_lerp_hi(float w, uint32_t a, uint32_t b) { float tmp, d; VPFX_MIX_LERP(1) return d; }
-
-// d = w * t + acc with t fp16 (low or high half of a dword), w and acc f32, f32 arithmetic: one v_fma_mix_f32.  The trilinear filter as a
-// weighted sum of the eight texels costs 8 of these per channel (32 per sample, as many as the two-instruction x-lerps alone) + 15
-// full-rate VALU for the weights, against 32 + 8 sub + 8 fma + 10 packed for lerp-by-lerp: ~176 vs ~221 issue cycles per sample
-// (v_fma_mix_f32 / packed f32 issue at 4.3 cycles per wave, plain f32 mul / add / fma at 2.6 -- profiles/r02_valu_rate_probe.txt).
+// d = w * t + acc with t fp16 (low or high half of a dword), w and acc f32, f32 arithmetic: one v_fma_mix_f32 -- the mixed-precision FMA
+// reads the packed halves directly, so no v_cvt_f32_f16 / unpacking is spent on the texel values.  (v_fma_mix_f32 issues at 4.3 cycles per
+// wave, plain f32 mul / add / fma at 2.6 -- profiles/r02_valu_rate_probe.txt.)
 #define VPFX_MIX_FMA(NAME, HI)                                                                                            \
     __device__ __forceinline__ float NAME(float w, uint32_t t, float acc)                                                 \
     {                                                                                                                     \
@@ -56,9 +46,6 @@ __device__ __forceinline__ float mix_lerp_hi(float w, uint32_t a, uint32_t b) { 
     }
 VPFX_MIX_FMA(mix_fma_lo, 0)
 VPFX_MIX_FMA(mix_fma_hi, 1)
-#ifndef VPFX_RM_WSUM
-#define VPFX_RM_WSUM 1
-#endif
 
 
 // Explicitly issued 16-byte loads for the two-samples-per-iteration loop: the compiler otherwise sinks the second
@@ -83,15 +70,6 @@ __device__ __forceinline__ void wait_pair(u32x4& a, u32x4& b)
 }
 __device__ __forceinline__ TexelPair as_pair(const u32x4 q) { return TexelPair{q[0], q[1], q[2], q[3]}; }
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
-__device__ __forceinline__ F4 lerp4(const F4& a, const F4& b, float t)
-{
-    return F4{lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)};
-}
-
-__device__ __forceinline__ F4 lerp_x(const TexelPair t, float w)
-{
-    return F4{mix_lerp_lo(w, t.rg0, t.rg1), mix_lerp_hi(w, t.rg0, t.rg1), mix_lerp_lo(w, t.ba0, t.ba1), mix_lerp_hi(w, t.ba0, t.ba1)};
-}
 
 // D3D11 float -> UNORM8 -> float round trip: clamp, scale, round to nearest
 __device__ __forceinline__ float unorm8(float x) { return floorf(fminf(fmaxf(x, 0.f), 1.f) * 255.0f + 0.5f) / 255.0f; }
@@ -237,41 +215,32 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
         const TexelPair r0 = *reinterpret_cast<const TexelPair*>(a.p), r1 = *reinterpret_cast<const TexelPair*>(a.p + NV);
         return QuadG{r0.rg0, r0.rg1, r1.rg0, r1.rg1, r0.ba0, r0.ba1, r1.ba0, r1.ba1};
     };
-    // grey: two channels (luminance in the low halves, density in the high halves), 8 v_fma_mix_f32 each
+    // Trilinear filter = bilinear weighted sum over (y, z) of the x0 texels and of the x1 texels (v_fma_mix_f32: f16 texel, f32 weight and
+    // accumulator), then one lerp in x: 6 weight instructions + 8 FMAs and 2 lerp instructions per channel (the full eight-weight sum costs
+    // 15 + 8 per channel).  Same value as the reference's lerp cascade up to f32 rounding (~1e-7).
+    // grey: two channels (luminance in the low halves, density in the high halves)
     auto filter_grey = [&](const QuadG& q, const Addr& a) -> F4 {
-        const float ax = 1.0f - a.wx, ay = 1.0f - a.wy, az = 1.0f - a.wz;
+        const float ay = 1.0f - a.wy, az = 1.0f - a.wz;
         const float w00 = ay * az, w10 = a.wy * az, w01 = ay * a.wz, w11 = a.wy * a.wz;         // [z][y]
-        const float w00a = w00 * ax, w00b = w00 * a.wx, w10a = w10 * ax, w10b = w10 * a.wx;
-        const float w01a = w01 * ax, w01b = w01 * a.wx, w11a = w11 * ax, w11b = w11 * a.wx;
-        const float lum = mix_fma_lo(w11b, q.d1, mix_fma_lo(w11a, q.d0, mix_fma_lo(w01b, q.c1, mix_fma_lo(w01a, q.c0,
-                          mix_fma_lo(w10b, q.b1, mix_fma_lo(w10a, q.b0, mix_fma_lo(w00b, q.a1, mix_fma_lo(w00a, q.a0, 0.f))))))));
-        const float den = mix_fma_hi(w11b, q.d1, mix_fma_hi(w11a, q.d0, mix_fma_hi(w01b, q.c1, mix_fma_hi(w01a, q.c0,
-                          mix_fma_hi(w10b, q.b1, mix_fma_hi(w10a, q.b0, mix_fma_hi(w00b, q.a1, mix_fma_hi(w00a, q.a0, 0.f))))))));
+        const float l0 = mix_fma_lo(w11, q.d0, mix_fma_lo(w01, q.c0, mix_fma_lo(w10, q.b0, mix_fma_lo(w00, q.a0, 0.f))));
+        const float l1 = mix_fma_lo(w11, q.d1, mix_fma_lo(w01, q.c1, mix_fma_lo(w10, q.b1, mix_fma_lo(w00, q.a1, 0.f))));
+        const float d0 = mix_fma_hi(w11, q.d0, mix_fma_hi(w01, q.c0, mix_fma_hi(w10, q.b0, mix_fma_hi(w00, q.a0, 0.f))));
+        const float d1 = mix_fma_hi(w11, q.d1, mix_fma_hi(w01, q.c1, mix_fma_hi(w10, q.b1, mix_fma_hi(w00, q.a1, 0.f))));
+        const float lum = lerpf(l0, l1, a.wx), den = lerpf(d0, d1, a.wx);
         return F4{lum, lum, lum, den};
     };
-    // x-lerp straight from the fp16 texels with mixed-precision FMAs (v_fma_mix_f32: f16 operands, f32 math), then y
-    // and z in f32.
     auto filter = [&](const Quad& q, const Addr& a) -> F4 {
-#if VPFX_RM_WSUM
-        // weighted sum of the eight texels (same value as the lerp cascade up to f32 rounding, ~1e-7)
-        const float ax = 1.0f - a.wx, ay = 1.0f - a.wy, az = 1.0f - a.wz;
+        const float ay = 1.0f - a.wy, az = 1.0f - a.wz;
         const float w00 = ay * az, w10 = a.wy * az, w01 = ay * a.wz, w11 = a.wy * a.wz;         // [z][y]
-        const float w00a = w00 * ax, w00b = w00 * a.wx, w10a = w10 * ax, w10b = w10 * a.wx;
-        const float w01a = w01 * ax, w01b = w01 * a.wx, w11a = w11 * ax, w11b = w11 * a.wx;
-        F4 c;
-        c.x = mix_fma_lo(w11b, q.t11.rg1, mix_fma_lo(w11a, q.t11.rg0, mix_fma_lo(w01b, q.t01.rg1, mix_fma_lo(w01a, q.t01.rg0,
-              mix_fma_lo(w10b, q.t10.rg1, mix_fma_lo(w10a, q.t10.rg0, mix_fma_lo(w00b, q.t00.rg1, mix_fma_lo(w00a, q.t00.rg0, 0.f))))))));
-        c.y = mix_fma_hi(w11b, q.t11.rg1, mix_fma_hi(w11a, q.t11.rg0, mix_fma_hi(w01b, q.t01.rg1, mix_fma_hi(w01a, q.t01.rg0,
-              mix_fma_hi(w10b, q.t10.rg1, mix_fma_hi(w10a, q.t10.rg0, mix_fma_hi(w00b, q.t00.rg1, mix_fma_hi(w00a, q.t00.rg0, 0.f))))))));
-        c.z = mix_fma_lo(w11b, q.t11.ba1, mix_fma_lo(w11a, q.t11.ba0, mix_fma_lo(w01b, q.t01.ba1, mix_fma_lo(w01a, q.t01.ba0,
-              mix_fma_lo(w10b, q.t10.ba1, mix_fma_lo(w10a, q.t10.ba0, mix_fma_lo(w00b, q.t00.ba1, mix_fma_lo(w00a, q.t00.ba0, 0.f))))))));
-        c.w = mix_fma_hi(w11b, q.t11.ba1, mix_fma_hi(w11a, q.t11.ba0, mix_fma_hi(w01b, q.t01.ba1, mix_fma_hi(w01a, q.t01.ba0,
-              mix_fma_hi(w10b, q.t10.ba1, mix_fma_hi(w10a, q.t10.ba0, mix_fma_hi(w00b, q.t00.ba1, mix_fma_hi(w00a, q.t00.ba0, 0.f))))))));
-        return c;
-#else
-        const F4 c00 = lerp_x(q.t00, a.wx), c10 = lerp_x(q.t10, a.wx), c01 = lerp_x(q.t01, a.wx), c11 = lerp_x(q.t11, a.wx);
-        return lerp4(lerp4(c00, c10, a.wy), lerp4(c01, c11, a.wy), a.wz);
-#endif
+        const float r0 = mix_fma_lo(w11, q.t11.rg0, mix_fma_lo(w01, q.t01.rg0, mix_fma_lo(w10, q.t10.rg0, mix_fma_lo(w00, q.t00.rg0, 0.f))));
+        const float r1 = mix_fma_lo(w11, q.t11.rg1, mix_fma_lo(w01, q.t01.rg1, mix_fma_lo(w10, q.t10.rg1, mix_fma_lo(w00, q.t00.rg1, 0.f))));
+        const float g0 = mix_fma_hi(w11, q.t11.rg0, mix_fma_hi(w01, q.t01.rg0, mix_fma_hi(w10, q.t10.rg0, mix_fma_hi(w00, q.t00.rg0, 0.f))));
+        const float g1 = mix_fma_hi(w11, q.t11.rg1, mix_fma_hi(w01, q.t01.rg1, mix_fma_hi(w10, q.t10.rg1, mix_fma_hi(w00, q.t00.rg1, 0.f))));
+        const float b0 = mix_fma_lo(w11, q.t11.ba0, mix_fma_lo(w01, q.t01.ba0, mix_fma_lo(w10, q.t10.ba0, mix_fma_lo(w00, q.t00.ba0, 0.f))));
+        const float b1 = mix_fma_lo(w11, q.t11.ba1, mix_fma_lo(w01, q.t01.ba1, mix_fma_lo(w10, q.t10.ba1, mix_fma_lo(w00, q.t00.ba1, 0.f))));
+        const float a0 = mix_fma_hi(w11, q.t11.ba0, mix_fma_hi(w01, q.t01.ba0, mix_fma_hi(w10, q.t10.ba0, mix_fma_hi(w00, q.t00.ba0, 0.f))));
+        const float a1 = mix_fma_hi(w11, q.t11.ba1, mix_fma_hi(w01, q.t01.ba1, mix_fma_hi(w10, q.t10.ba1, mix_fma_hi(w00, q.t00.ba1, 0.f))));
+        return F4{lerpf(r0, r1, a.wx), lerpf(g0, g1, a.wx), lerpf(b0, b1, a.wx), lerpf(a0, a1, a.wx)};
     };
     auto blend = [&](const F4& c, float density) {
         const float bf = __builtin_amdgcn_rcpf(1.0f + density);                           // :272
@@ -461,7 +430,7 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #define VPFX_RM_WAVES_PARTIAL 3   // partial images + flag paths (debug views of a slab): the one combination that needs > 128 VGPRs
 #endif
 #ifndef VPFX_RM_WAVES_GREY
-#define VPFX_RM_WAVES_GREY 5      // the plain grey-brick kernel needs 99 VGPRs: 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3)
+#define VPFX_RM_WAVES_GREY 5      // the plain grey-brick kernel needs 93 VGPRs: 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3; the slab variant would spill 2)
 #endif
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY>
 __global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : (GREY && !PARTIAL && !FLAGS) ? VPFX_RM_WAVES_GREY : VPFX_RM_WAVES)
