@@ -228,20 +228,16 @@ def main():
         nv = sc.nv
         fill_ms, rm_ms, bin_ms = float(np.mean(k_fill)), float(np.mean(k_rm)), float(np.mean(k_bin))
         # algorithmic bytes; rank-0 slab for N > 1
-        # bricks are counted at the bytes per voxel the context actually stores (8 = RGBA16F, SURVEY's figure; 4 = grey-ambient pairs)
+        # bricks are counted at the bytes per voxel the context actually stores (8 in both formats = SURVEY's figure)
         lds_path = args.cubemap == "r8" and not args.no_lds_cubemap
         bpv = st.get("brick_bytes_per_voxel", 8)
         fill_bytes = st["occupied_mv"] * (bpv * nv ** 3 + 8 * nv ** 2) + 84 * st["pairs"]
         rm_bytes = st["bricks_sampled"] * bpv * nv ** 3 + 16 * sc.width * sc.height
-        fill_bytes_rgba = st["occupied_mv"] * (8 * nv ** 3 + 8 * nv ** 2) + 84 * st["pairs"]
-        rm_bytes_rgba = st["bricks_sampled"] * 8 * nv ** 3 + 16 * sc.width * sc.height
         roofs = {
             "fill": {"bound": "hbm", "kernel": "k_fill_lds" if lds_path else "k_fill", "achieved": fill_bytes / (fill_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "bytes_per_launch": fill_bytes, "avg_ms": fill_ms, "brick_bytes_per_voxel": bpv,
-                     "frac_at_8B_per_voxel": fill_bytes_rgba / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "unit": "GB/s", "bytes_per_launch": fill_bytes, "avg_ms": fill_ms, "brick_bytes_per_voxel": bpv},
             "raymarch": {"bound": "hbm", "kernel": "k_raymarch", "achieved": rm_bytes / (rm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "bytes_per_launch": rm_bytes, "avg_ms": rm_ms, "brick_bytes_per_voxel": bpv,
-                         "frac_at_8B_per_voxel": rm_bytes_rgba / (rm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "requested_GBps_per_sample_footprint": st["samples"] * 8 * bpv / (rm_ms * 1e-3) / 1e9},
         }
         # HBM traffic per launch measured with rocprofv3 PMC passes (scripts/gpu_prof2.sh -> profiles/*traffic*.json);
@@ -269,9 +265,11 @@ def main():
                                     if lds_path else
                                     ("the CU's single L1/TA path: one divergent wave-wide footprint gather per covered slice (~65 cycles per "
                                      "wave-slice per CU against ~38 of VALU); HBM at ~0.65 TB/s"))
-        roofs["raymarch"]["limiter"] = ("L1 (TCP) tag rate: 4 footprint loads per sample, each wave-load touches ~20-26 different 128-B brick rows; "
-                                        "TCP busy 96 % of the kernel, ~26.5 L1 cycles per wave-load (profiles/r02_pmc_memory_pipes_C3_r8.txt); "
-                                        "VALU (~48 instr/sample) hides underneath; HBM at ~1.6 TB/s")
+        roofs["raymarch"]["limiter"] = (("VALU issue: ~51 VALU per wave-sample, SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles ~ 0.78, 59 % of the lanes active; two 16-B "
+                                         "footprint loads per sample (grey z-pair bricks), L1 at ~60 % of its access rate; HBM at ~2.5 TB/s")
+                                        if st.get("brick_format", 0) == 1 else
+                                        ("L1 (TCP): four 16-B footprint loads per sample, one lane quad per L1 cycle at best: TCP busy 96 %, ~26.5 L1 "
+                                         "cycles per wave-load (profiles/r02_l1_gather_probe.txt); VALU hides underneath; HBM at ~1.6 TB/s"))
         smax = [float(x) for x in stage_max.tolist()]
         # whole-job algorithmic bytes (all ranks): bricks + light map + pair records; bricks sampled + the image
         fill_bytes_job = occupied * (bpv * nv ** 3 + 8 * nv ** 2) + 84 * pairs
@@ -293,8 +291,8 @@ def main():
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
                        "cubemap": ("R8 (8-bit like the reference's asset; LDS-resident in k_fill)" if args.cubemap == "r8" and not args.no_lds_cubemap
                                    else "R8 on the global f32 footprint table" if args.cubemap == "r8" else "f32 texels, global footprint table"),
-                       "brick_storage": ("luminance|density fp16 pairs, 4 B/voxel (grey ambient: r = g = b bit for bit); roofline bytes count 4 B/voxel, "
-                                         "frac_at_8B_per_voxel keeps SURVEY 8(d)'s RGBA16F figure for comparison with round 1" if bpv == 4 else "RGBA16F, 8 B/voxel"),
+                       "brick_storage": ("grey z-pair entries: (luminance|density)(z), (luminance|density)(z+1), 8 B/voxel (grey ambient: r = g = b bit for bit)"
+                                         if st.get("brick_format", 0) == 1 else "RGBA16F, 8 B/voxel"),
                        "parallelism": f"zslab{world}" + (f" ({args.exchange} exchange)" if world > 1 else ""), "slabs": bounds if world > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),

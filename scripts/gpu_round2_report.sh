@@ -4,6 +4,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
 PROF_DIR=prof_r2 bash scripts/gpu_prof_r2.sh > gpurun_out/r2/prof_r8.log 2>&1
 PROF_DIR=prof_r2_f32 BENCH_ARGS="--cubemap f32" bash scripts/gpu_prof_r2.sh > gpurun_out/r2/prof_f32.log 2>&1
+# the bench lines below report roofline.traffic from the PMC passes just made (same kernel sources; copy them into profiles/ here as well)
+cp gpurun_out/prof_r2/traffic.json profiles/traffic_C3_r8.json; cp gpurun_out/prof_r2_f32/traffic.json profiles/traffic_C3_f32.json
 for cfg in C1 C2; do
   timeout 600 python bench.py --config $cfg --steps 200 --warmup 5 2> /dev/null | tail -1 > gpurun_out/r2/bench_$cfg.json
 done

@@ -472,7 +472,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             }
 
             // propagate + store this chunk                                               Fill.shader:231-269
-            // volumeTex[int3(xy, slice)]: RGBA16F, or -- grey ambient: r = g = b bit for bit -- luminance | density, 4 bytes per voxel.
+            // volumeTex[int3(xy, slice)]: RGBA16F, or -- grey ambient: r = g = b bit for bit -- the z-pair entry (luminance | density)(z), (z + 1).
             // The format is wave-uniform: the branch is taken once per chunk, outside the 32 unrolled slices.
             auto propagate_store = [&](auto grey_tag) {
                 constexpr bool GREYB = decltype(grey_tag)::value;

@@ -50,7 +50,7 @@ struct FillConsts {
     float D_over_255;             // displacement scale for byte texels (R8 cube map in LDS): net = (D/255) * bilinear(bytes) + (1 - D)
     int   lds_pitch;              // row pitch of the padded byte table (cube_u8_pitch: S + 2 rounded up for bank spread)
     int   d_is_one;               // displacement scale == 1 exactly (net displacement can be 0: see cube_shade)
-    int   grey;                   // ambient r == g == b: bricks stored as (luminance, density), 4 bytes per voxel
+    int   grey;                   // ambient r == g == b: bricks stored as (luminance, density) z-pair entries (raymarch.hip)
 };
 
 struct RmConsts {
