@@ -334,6 +334,21 @@ k_col_rank(const int* __restrict__ weight, int nxy, int* __restrict__ colorder)
     if (threadIdx.x < 64 && i < nxy) colorder[s_rank[threadIdx.x]] = i;
 }
 
+// Chained fill (fill.hip): position of every occupied MV of the owned slab among the occupied MVs of its (xx, yy) column, front to back,
+// and the number of occupied MVs per column.
+__global__ void __launch_bounds__(256)
+k_col_ordinal(const int* __restrict__ brick_index, int nxy, int z0, int z1, int* __restrict__ ord, int* __restrict__ colcount)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nxy) return;
+    int n = 0;
+    for (int zz = z0; zz < z1; ++zz) {
+        const int mi = zz * nxy + i;
+        if (brick_index[mi] >= 0) ord[mi] = n++;
+    }
+    colcount[i] = n;
+}
+
 __global__ void __launch_bounds__(256)
 k_col_identity(int nxy, int* __restrict__ colorder)
 {
@@ -387,6 +402,7 @@ int launch_bin(vp_ctx* c)
     } else {
         hipLaunchKernelGGL(k_col_identity, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, nxy, c->d_colorder);
     }
+    hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
     VP_HIP(hipGetLastError());
     // totals are needed on the host to size the pair and brick pools
     VP_HIP(hipMemcpyAsync(&c->h_meta, c->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, c->stream));

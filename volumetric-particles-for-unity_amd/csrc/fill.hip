@@ -247,17 +247,51 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
     }
 }
 
+// Chained fill.  The unit of work of the persistent kernel is ONE metavoxel of one 8x8-column tile, not the tile's whole walk along the
+// light axis: 16 x fewer, 32 x longer units (C3: 16 384 walks of up to 3.4 x the mean for 4 096 waves) left the waves idle for 18 % of the
+// kernel (SQ_WAVE_CYCLES), per-metavoxel units (181 k) do not.  What a walk carried in a register -- the light transmitted so far, one
+// float per voxel column -- is handed from the unit of one occupied metavoxel to the unit of the next one in that column through memory:
+// one 64-bit word per column, tag << 32 | float bits, written and polled with relaxed agent-scope atomics (single-location coherence is
+// all it needs: no fence, no L2 write-back).  Units are claimed in z-major order, so the producer of a word was always claimed earlier, by
+// a wave that is running and never waits for a later unit: no deadlock; and a consumer only looks at the word after its own
+// accumulation, ~70 us after claiming, when the producer -- claimed >= one metavoxel layer earlier -- has long finished.
+struct FillChain {
+    unsigned long long* words;    // [LH][LW]
+    const int* ord;               // [n3] occupied MVs of the column in front of this one
+    const int* colcount;          // [nxy]
+    const int* occ_list;          // occupied MVs of the slab, z-major
+    uint32_t tag_base;            // launch sequence number x (Nz + 1): tags of different launches never collide
+};
+__device__ __forceinline__ float chain_wait(const unsigned long long* w, uint32_t tag)
+{
+    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((uint32_t)(v >> 32) != tag) {
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __uint_as_float((uint32_t)v);
+}
+__device__ __forceinline__ void chain_publish(unsigned long long* w, float v, uint32_t tag)
+{
+    __hip_atomic_store(w, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
 // (propagation with T_in = 1) to light_out.
+#ifndef VPFX_FILL_CHAIN
+#define VPFX_FILL_CHAIN 1       // persistent LDS kernel: per-metavoxel units with the light handed on through memory (0: whole-column units)
+#endif
 #ifndef VPFX_FILL_WAVES
 #define VPFX_FILL_WAVES 3      // min waves per SIMD: caps the kernels at 168 VGPRs (without the cap hipcc takes 165-174 and NV = 64 drops to 2 waves)
 #endif
 // One wave's share of the fill: an 8x8-column tile (this lane: column px, py) of metavoxel column (xx, yy), walked along the light
 // axis zz = z0 .. z1.  TAB = 0: cube-map footprints from the global f32 pair table (p_cubequads);  TAB = 1 / 2: R8 cube map
 // resident in LDS (1: S = 128, row pitch 130 as instruction immediates; 2: any S, pitch from FillConsts).
-template <int NV, bool EXACT, int MODE, int TAB>
+// CHAIN: only metavoxel zz_a of the column, light handed on through `ch` (see FillChain); otherwise zz_a .. zz_b - 1 with the light in a register.
+template <int NV, bool EXACT, int MODE, int TAB, bool CHAIN = false>
 __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts& f, FILL_PTR_PARAMS, const int xx, const int yy, const int px,
-                                          const int py, const int lane, const unsigned lds_base)
+                                          const int py, const int lane, const unsigned lds_base, const int zz_a, const int zz_b,
+                                          const FillChain ch = FillChain{})
 {
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
     constexpr int PIPE = TAB == 0 ? VPFX_FILL_PIPE : VPFX_FILL_PIPE_LDS;   // footprint loads in flight per wave
@@ -279,10 +313,11 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
     float one_minus_D = f.one_minus_D;
     asm volatile("" : "+v"(one_minus_D));                                                // keep it in a VGPR (see cube_shade)
 
-    for (int zz = g.z0; zz < g.z1; ++zz) {                                               // z-major = draw order VPR.cs:505
+    for (int zz = zz_a; zz < zz_b; ++zz) {                                               // z-major = draw order VPR.cs:505
         const int mi = (zz * g.Ny + yy) * g.Nx + xx;
         const int bi = p_brick_index[mi];
         if (bi < 0) continue;                                                            // empty MV skipped    VPR.cs:511
+        const int ord = CHAIN ? ch.ord[mi] : 0;
         const int off = p_offsets[mi];
         const int n = p_offsets[mi + 1] - off;
         const float mvx = p_mvPos[3 * mi], mvy = p_mvPos[3 * mi + 1], mvz = p_mvPos[3 * mi + 2];
@@ -296,8 +331,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
         const float q = (lsSceneDepth - lz0) / g.one;
         const int shadowIndex = !(q < 2.0e9f) ? 2000000000 : (q < -2.0e9f ? -2000000000 : (int)q);
 
-        float T = (zz == 0) ? f.init_light : prop;                                       // :224
-        prop = T;
+        float T = 0.f;
+        if (!CHAIN) { T = (zz == 0) ? f.init_light : prop; prop = T; }                   // :224
         uint2* brick = p_bricks + (size_t)bi * NV * NV * NV;
         float2* scratch = p_dens_ao + (size_t)bi * NV * NV * NV;
 
@@ -471,6 +506,12 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             }
             }
 
+            if (CHAIN && c0 == 0) {
+                // the light that reaches this metavoxel: what the column's previous occupied metavoxel handed on (its unit was claimed earlier)
+                if (ord > 0) prop = chain_wait(ch.words + lmi, ch.tag_base + (uint32_t)ord);
+                T = (zz == 0) ? f.init_light : prop;                                     // :224
+                prop = T;
+            }
             // propagate + store this chunk                                               Fill.shader:231-269
             // volumeTex[int3(xy, slice)]: RGBA16F, or -- grey ambient: r = g = b bit for bit -- the z-pair entry (luminance | density)(z), (z + 1).
             // The format is wave-uniform: the branch is taken once per chunk, outside the 32 unrolled slices.
@@ -504,8 +545,13 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             };
             if (MODE == 0 && f.grey) propagate_store(std::true_type{}); else propagate_store(std::false_type{});
         }
+        if (CHAIN) {
+            // the column's last occupied metavoxel writes the light map (every other value of the column is only ever seen by the next unit)
+            if (ord + 1 == ch.colcount[yy * g.Nx + xx]) p_light_out[lmi] = prop;          // lightPropogationTex[..] :250
+            else chain_publish(ch.words + lmi, prop, ch.tag_base + (uint32_t)ord + 1u);
+        }
     }
-    p_light_out[lmi] = prop;                                                             // lightPropogationTex[..] :250
+    if (!CHAIN) p_light_out[lmi] = prop;                                                 // lightPropogationTex[..] :250
 }
 
 // Launch shape of the global-table path: workgroup = 16x16 voxel columns of one MV column (4 waves, each an 8x8 tile); MV columns
@@ -523,7 +569,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
     const int px = (tile % TW) * 16 + (wave & 1) * 8 + (lane & 7);      // wave = 8x8 columns: most compact footprint,
     const int py = (tile / TW) * 16 + (wave >> 1) * 8 + (lane >> 3);    // highest lane utilisation in covered slices
     fill_tile<NV, EXACT, MODE, 0>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
-                                  p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, 0u);
+                                  p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, 0u, g.z0, g.z1);
 }
 
 // R8 cube maps (the reference's own asset format): the whole map, 6 (S+2)^2 bytes with the clamp border replicated (99 KB at
@@ -535,7 +581,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
 template <int NV, int MODE, int TAB>
 __global__ void __launch_bounds__(64 * VPFX_FILL_LDS_WAVES)
 k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
-           int nitems)
+           int nitems, FillChain ch)
 {
     extern __shared__ uint32_t lds_cube[];
     for (int i = threadIdx.x; i < table_dwords; i += 64 * VPFX_FILL_LDS_WAVES) lds_cube[i] = p_cube_u8[i];
@@ -548,12 +594,21 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
         if (lane == 0) item = atomicAdd(p_counter, 1);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= nitems) break;
-        const int col = p_colorder[item / TPC];
         const int sub = item % TPC;
-        const int xx = col % g.Nx, yy = col / g.Nx;
         const int px = (sub % T8) * 8 + (lane & 7), py = (sub / T8) * 8 + (lane >> 3);
+#if VPFX_FILL_CHAIN
+        // unit = (occupied metavoxel, tile), metavoxels z-major (a unit's producer is always claimed before it)
+        const int mi = ch.occ_list[item / TPC];
+        const int nxy = g.Nx * g.Ny, zz = mi / nxy, col = mi - zz * nxy;
+        const int xx = col % g.Nx, yy = col / g.Nx;
+        fill_tile<NV, false, MODE, TAB, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap,
+                                              p_light_in, p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, zz, zz + 1, ch);
+#else
+        const int col = p_colorder[item / TPC];
+        const int xx = col % g.Nx, yy = col / g.Nx;
         fill_tile<NV, false, MODE, TAB>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
-                                        p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base);
+                                        p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, g.z0, g.z1);
+#endif
     }
 }
 
@@ -695,12 +750,30 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     static bool granted = false;                      // per instantiation (the attribute sticks to the function)
     if (!granted) { int rc = allow_big_lds(c, kernel, 160 * 1024); if (rc) return rc; granted = true; }
     constexpr int TPC = (NV / 8) * (NV / 8);
+    FillChain ch{};
+#if VPFX_FILL_CHAIN
+    const int nitems = c->h_meta.occupied * TPC;
+    // columns without an occupied metavoxel keep the incoming light; the others are overwritten by their last unit
+    const size_t lm = (size_t)c->g.Nx * NV * c->g.Ny * NV;
+    if (MODE == 0 && P.light_in) { if (P.light_in != P.light_out) VP_HIP(hipMemcpyAsync(P.light_out, P.light_in, lm * sizeof(float), hipMemcpyDeviceToDevice, c->stream)); }
+    else { int rc = launch_fill_value(c, P.light_out, lm, 1.0f); if (rc) return rc; }
+    const uint32_t span = (uint32_t)c->g.Nz + 1u;
+    if (c->chain_seq >= 0xffffffffu / span - 1u) {              // tags would wrap: start over with cleared words
+        VP_HIP(hipMemsetAsync(c->d_chain, 0, lm * sizeof(unsigned long long), c->stream));
+        c->chain_seq = 0;
+    }
+    ch.words = c->d_chain; ch.ord = c->d_ord; ch.colcount = c->d_colcount; ch.occ_list = c->d_occ_list;
+    ch.tag_base = c->chain_seq * span;
+    ++c->chain_seq;
+    if (nitems == 0) return VP_OK;
+#else
     const int nitems = c->g.Nx * c->g.Ny * TPC;
+#endif
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     constexpr int WV = VPFX_FILL_LDS_WAVES;
     const int grid = nitems < WV * c->num_cus ? (nitems + WV - 1) / WV : c->num_cus;   // one persistent workgroup per CU
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WV), bytes, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), (const uint32_t*)c->d_cube_u8,
-                       (int)(bytes / 4), c->d_work_counter, nitems);
+                       (int)(bytes / 4), c->d_work_counter, nitems, ch);
     return VP_OK;
 }
 

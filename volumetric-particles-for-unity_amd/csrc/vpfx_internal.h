@@ -130,6 +130,10 @@ struct vp_ctx {
     size_t cube_u8_cap = 0;       // bytes allocated
     int cube_u8_S = 0;            // 0 = no byte table resident (f32 cube map, or too large for LDS)
     int* d_work_counter = nullptr;// tile counter of the persistent fill
+    int* d_ord = nullptr;         // [n3] per occupied MV: occupied MVs of its (xx, yy) column in front of it (owned slab)   (bin.hip)
+    int* d_colcount = nullptr;    // [nxy] occupied MVs per column (owned slab)
+    unsigned long long* d_chain = nullptr;   // [LH][LW] light hand-off words of the chained fill: tag << 32 | float bits     (fill.hip)
+    uint32_t chain_seq = 0;       // fill launches since the hand-off words were last cleared
     int num_cus = 0;
     float* d_depthmap = nullptr;
     bool have_depthmap = false;
