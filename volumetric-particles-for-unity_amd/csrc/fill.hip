@@ -556,20 +556,37 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 
 // Launch shape of the global-table path: workgroup = 16x16 voxel columns of one MV column (4 waves, each an 8x8 tile); MV columns
 // heaviest first.
-template <int NV, bool EXACT, int MODE>
+// CHAIN: one workgroup per (occupied metavoxel, 16x16-column tile), metavoxels z-major, light handed on through FillChain; the unit is
+// taken from a counter when the workgroup STARTS (not from blockIdx: nothing guarantees dispatch order), so a unit's producer always
+// started before it.  Otherwise one workgroup walks the tile's whole column (the per-metavoxel entry point, whose light goes through the
+// light map like the reference's UAV).
+template <int NV, bool EXACT, int MODE, bool CHAIN>
 __global__ void __launch_bounds__(256, VPFX_FILL_WAVES)
-k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS)
+k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restrict__ p_counter)
 {
     constexpr int TW = NV / 16;                      // 16x16-column tiles per MV edge
     constexpr int TPM = TW * TW;
-    const int col = p_colorder[blockIdx.x / TPM];
-    const int tile = blockIdx.x % TPM;
-    const int xx = col % g.Nx, yy = col / g.Nx;
+    int unit = blockIdx.x;
+    if (CHAIN) {
+        __shared__ int sh_unit;
+        if (threadIdx.x == 0) sh_unit = atomicAdd(p_counter, 1);
+        __syncthreads();
+        unit = sh_unit;
+    }
+    const int tile = unit % TPM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = (tile % TW) * 16 + (wave & 1) * 8 + (lane & 7);      // wave = 8x8 columns: most compact footprint,
     const int py = (tile / TW) * 16 + (wave >> 1) * 8 + (lane >> 3);    // highest lane utilisation in covered slices
-    fill_tile<NV, EXACT, MODE, 0>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
-                                  p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, 0u, g.z0, g.z1);
+    if (CHAIN) {
+        const int mi = ch.occ_list[unit / TPM];
+        const int nxy = g.Nx * g.Ny, zz = mi / nxy, col = mi - zz * nxy;
+        fill_tile<NV, EXACT, MODE, 0, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
+                                            p_light_out, p_bricks, p_dens_ao, p_ws, col % g.Nx, col / g.Nx, px, py, lane, 0u, zz, zz + 1, ch);
+    } else {
+        const int col = p_colorder[unit / TPM];
+        fill_tile<NV, EXACT, MODE, 0>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
+                                      p_light_out, p_bricks, p_dens_ao, p_ws, col % g.Nx, col / g.Nx, px, py, lane, 0u, g.z0, g.z1);
+    }
 }
 
 // R8 cube maps (the reference's own asset format): the whole map, 6 (S+2)^2 bytes with the clamp border replicated (99 KB at
@@ -742,6 +759,27 @@ int allow_big_lds(vp_ctx* c, K kernel, size_t bytes)
     return VP_OK;
 }
 
+// Host side of a chained launch: light map preset for the columns without an occupied metavoxel (the others are overwritten by their last
+// unit), a fresh tag range for the hand-off words.
+int chain_begin(vp_ctx* c, const FillPtrs& P, int mode, FillChain& ch)
+{
+    const size_t lm = (size_t)c->g.Nx * c->g.nv * c->g.Ny * c->g.nv;
+    if (mode == 0 && P.light_in) {
+        if (P.light_in != P.light_out) VP_HIP(hipMemcpyAsync(P.light_out, P.light_in, lm * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        int rc = launch_fill_value(c, P.light_out, lm, 1.0f); if (rc) return rc;
+    }
+    const uint32_t span = (uint32_t)c->g.Nz + 1u;
+    if (c->chain_seq >= 0xffffffffu / span - 1u) {              // tags would wrap: start over with cleared words
+        VP_HIP(hipMemsetAsync(c->d_chain, 0, lm * sizeof(unsigned long long), c->stream));
+        c->chain_seq = 0;
+    }
+    ch.words = c->d_chain; ch.ord = c->d_ord; ch.colcount = c->d_colcount; ch.occ_list = c->d_occ_list;
+    ch.tag_base = c->chain_seq * span;
+    ++c->chain_seq;
+    return VP_OK;
+}
+
 template <int NV, int MODE, int TAB>
 int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
 {
@@ -753,18 +791,7 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     FillChain ch{};
 #if VPFX_FILL_CHAIN
     const int nitems = c->h_meta.occupied * TPC;
-    // columns without an occupied metavoxel keep the incoming light; the others are overwritten by their last unit
-    const size_t lm = (size_t)c->g.Nx * NV * c->g.Ny * NV;
-    if (MODE == 0 && P.light_in) { if (P.light_in != P.light_out) VP_HIP(hipMemcpyAsync(P.light_out, P.light_in, lm * sizeof(float), hipMemcpyDeviceToDevice, c->stream)); }
-    else { int rc = launch_fill_value(c, P.light_out, lm, 1.0f); if (rc) return rc; }
-    const uint32_t span = (uint32_t)c->g.Nz + 1u;
-    if (c->chain_seq >= 0xffffffffu / span - 1u) {              // tags would wrap: start over with cleared words
-        VP_HIP(hipMemsetAsync(c->d_chain, 0, lm * sizeof(unsigned long long), c->stream));
-        c->chain_seq = 0;
-    }
-    ch.words = c->d_chain; ch.ord = c->d_ord; ch.colcount = c->d_colcount; ch.occ_list = c->d_occ_list;
-    ch.tag_base = c->chain_seq * span;
-    ++c->chain_seq;
+    { int rc = chain_begin(c, P, MODE, ch); if (rc) return rc; }
     if (nitems == 0) return VP_OK;
 #else
     const int nitems = c->g.Nx * c->g.Ny * TPC;
@@ -789,7 +816,17 @@ template <int NV>
 int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 {
     constexpr int TPM = (NV / 16) * (NV / 16);
-    const dim3 grid(c->g.Nx * c->g.Ny * TPM), block(256);
+    const dim3 block(256);
+    if (mode == 2) {
+        hipLaunchKernelGGL((k_fill_finish<NV>), dim3(c->g.Nx * c->g.Ny * TPM), block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), c->finish_tau_all,
+                           c->finish_n_before, (size_t)c->g.Nx * NV * c->g.Ny * NV);
+        return VP_OK;
+    }
+    FillChain ch{};
+    { int rc = chain_begin(c, P, mode, ch); if (rc) return rc; }
+    if (c->h_meta.occupied == 0) return VP_OK;
+    const dim3 grid(c->h_meta.occupied * TPM);
+    VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
 #if VPFX_FILL_LDS_TILE
     static const int dbg_lds = 4 * 2 * (NV < 32 ? NV : 32) * 64 * (int)sizeof(float);        // the four waves' (density, ao) tiles
 #else
@@ -797,14 +834,11 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
 #endif
     const int tl = VPFX_FILL_LDS_TILE ? dbg_lds : 0;
     if (mode == 0) {
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
-        else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, dbg_lds, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
-    } else if (mode == 1) {
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
-        else       hipLaunchKernelGGL((k_fill<NV, false, 1>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P));
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
+        else       hipLaunchKernelGGL((k_fill<NV, false, 0, true>), grid, block, dbg_lds, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
     } else {
-        hipLaunchKernelGGL((k_fill_finish<NV>), grid, block, 0, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), c->finish_tau_all, c->finish_n_before,
-                           (size_t)c->g.Nx * NV * c->g.Ny * NV);
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
+        else       hipLaunchKernelGGL((k_fill<NV, false, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
     }
     return VP_OK;
 }
@@ -860,8 +894,8 @@ int launch_fill_one(vp_ctx* c, int xx, int yy, int zz)
 #define VPFX_FILL_ONE(NV)                                                                                            \
     do {                                                                                                              \
         const dim3 grid((NV / 16) * (NV / 16));                                                                       \
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P));  \
-        else       hipLaunchKernelGGL((k_fill<NV, false, 0>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P)); \
+        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr);  \
+        else       hipLaunchKernelGGL((k_fill<NV, false, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr); \
     } while (0)
     switch (c->g.nv) {
     case 16: VPFX_FILL_ONE(16); break;
