@@ -246,9 +246,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{args.cubemap}.json")
         if world == 1 and os.path.exists(tpath):
             traffic = json.load(open(tpath))
-            if traffic.get("kernel_sources_sha") != kernel_sources_sha() or args.no_lds_cubemap:
+            if traffic.get("kernel_sources_sha") != kernel_sources_sha() or args.no_lds_cubemap or args.no_grey:
                 tnote = (f"profiles/{os.path.basename(tpath)} was measured on other kernel sources "
-                         f"({traffic.get('kernel_sources_sha')} != {kernel_sources_sha()}): not reported")
+                         f"({traffic.get('kernel_sources_sha')} != {kernel_sources_sha()}) or another code path (A/B switch): not reported")
                 traffic = {}
         for name, r in roofs.items():
             r["frac"] = r["achieved"] / r["peak"]
