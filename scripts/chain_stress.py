@@ -1,6 +1,6 @@
 """Stress of the chained fill's light hand-off (fill.hip, FillChain): the light map is the end of every column's chain, so one stale or torn
 hand-off anywhere changes it.  Fills the config `reps` times and prints the set of distinct (light map, sampled bricks) fingerprints -- it must
-have ONE element, and the same one for a library built with -DVPFX_FILL_CHAIN=0 (scripts/gpu_ab.sh swaps libraries).
+have ONE element (and had the same one for the last build whose fill walked whole columns with the light in a register).
 usage: chain_stress.py [config] [reps]"""
 import sys, os, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -219,7 +219,7 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
     if ((rc = dev_alloc(c, &c->d_mvPos, c->n3 * 3)) || (rc = dev_alloc(c, &c->d_count, c->n3)) ||
         (rc = dev_alloc(c, &c->d_offsets, c->n3 + 1)) || (rc = dev_alloc(c, &c->d_cursor, c->n3)) ||
         (rc = dev_alloc(c, &c->d_brick_index, c->n3)) || (rc = dev_alloc(c, &c->d_occ_list, c->n3)) ||
-        (rc = dev_alloc(c, &c->d_colorder, nxy)) || (rc = dev_alloc(c, &c->d_onecol, 2)) || (rc = dev_alloc(c, &c->d_work_counter, 1)) || (rc = dev_alloc(c, &c->d_colweight, nxy)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
+        (rc = dev_alloc(c, &c->d_onecol, 2)) || (rc = dev_alloc(c, &c->d_work_counter, 1)) || (rc = dev_alloc(c, &c->d_meta, 1)) ||
         (rc = dev_alloc(c, &c->d_ord, c->n3)) || (rc = dev_alloc(c, &c->d_colcount, nxy)) || (rc = dev_alloc(c, &c->d_chain, lightmap_elems(c))) ||
         (rc = dev_alloc(c, (int4**)&c->d_scan_totals, (c->n3 + 1023) / 1024 + 1)) ||
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
@@ -240,7 +240,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
-                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_colorder, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_colweight, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
+                   c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
                    c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);

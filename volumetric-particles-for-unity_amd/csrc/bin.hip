@@ -6,7 +6,7 @@
 //   k_scan_*       two-launch tiled exclusive scan: CSR offsets, brick slots (z-major = draw order), totals
 //   k_bin<SCATTER> same walk, atomic cursor -> unsorted CSR lists
 //   k_sort_lists   per occupied MV: rank sort -> ascending particle index (the reference's list order, :452)
-//   k_col_weight/k_col_rank   MV columns sorted by work, heaviest first (launch order of the persistent fill kernel)
+//   k_col_ordinal  per occupied MV: how many occupied MVs of its column lie in front of it (chained fill, fill.hip)
 //
 // The reference clears N^3 managed lists and rebuilds a 4x4 inverse per candidate on the CPU; here the bins
 // are a CSR over an occupied-brick list and the per-MV inverse collapses to one shared 3x3 (rowsb) plus a
@@ -292,47 +292,6 @@ k_sort_lists(const int* __restrict__ occ_list, const int* __restrict__ offsets, 
     }
 }
 
-// MV columns ordered by pair count, heaviest first (longest-processing-time-first dispatch of the fill).
-#define COL_CAP 8192
-__global__ void __launch_bounds__(256)
-k_col_weight(const int* __restrict__ count, int nxy, int z0, int z1, int* __restrict__ weight)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nxy) return;
-    int wsum = 0;
-#pragma unroll 16
-    for (int zz = z0; zz < z1; ++zz) { const int cnt = count[zz * nxy + i]; wsum += cnt ? cnt + 8 : 0; }
-    weight[i] = wsum;
-}
-
-// rank of 64 columns per workgroup: wave w counts, for each of them, the heavier columns among the w-th sixteenth of all
-__global__ void __launch_bounds__(1024)
-k_col_rank(const int* __restrict__ weight, int nxy, int* __restrict__ colorder)
-{
-    __shared__ __attribute__((aligned(16))) int s_work[COL_CAP];
-    __shared__ int s_rank[64];
-    const int npad = (nxy + 3) & ~3;
-    for (int i = threadIdx.x; i < npad; i += 1024) s_work[i] = i < nxy ? weight[i] : -1;     // padding never outranks a column
-    if (threadIdx.x < 64) s_rank[threadIdx.x] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), chunk = threadIdx.x >> 6;
-    const int per = (((npad + 15) / 16) + 3) & ~3;
-    const int j0 = chunk * per, j1 = min(npad, j0 + per);
-    if (i < nxy) {
-        const int w = s_work[i];
-        int r = 0;
-        for (int j = j0; j < j1; j += 4) {                   // one 16-byte LDS broadcast read per four candidates
-            const int4 q = *reinterpret_cast<const int4*>(&s_work[j]);
-            r += (q.x > w || (q.x == w && j < i)) ? 1 : 0;
-            r += (q.y > w || (q.y == w && j + 1 < i)) ? 1 : 0;
-            r += (q.z > w || (q.z == w && j + 2 < i)) ? 1 : 0;
-            r += (q.w > w || (q.w == w && j + 3 < i)) ? 1 : 0;
-        }
-        atomicAdd(&s_rank[threadIdx.x & 63], r);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64 && i < nxy) colorder[s_rank[threadIdx.x]] = i;
-}
 
 // Chained fill (fill.hip): position of every occupied MV of the owned slab among the occupied MVs of its (xx, yy) column, front to back,
 // and the number of occupied MVs per column.
@@ -347,13 +306,6 @@ k_col_ordinal(const int* __restrict__ brick_index, int nxy, int z0, int z1, int*
         if (brick_index[mi] >= 0) ord[mi] = n++;
     }
     colcount[i] = n;
-}
-
-__global__ void __launch_bounds__(256)
-k_col_identity(int nxy, int* __restrict__ colorder)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nxy) colorder[i] = i;
 }
 
 }  // namespace
@@ -396,12 +348,6 @@ int launch_bin(vp_ctx* c)
     if (prefixed) hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(SCAN_TILE), 0, c->stream, (TileTotals*)c->d_scan_totals, ntiles);
     hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
                        (const TileTotals*)c->d_scan_totals, ntiles, prefixed, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
-    if (nxy <= COL_CAP) {
-        hipLaunchKernelGGL(k_col_weight, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, c->d_count, nxy, g.z0, g.z1, c->d_colweight);
-        hipLaunchKernelGGL(k_col_rank, dim3((nxy + 63) / 64), dim3(1024), 0, c->stream, c->d_colweight, nxy, c->d_colorder);
-    } else {
-        hipLaunchKernelGGL(k_col_identity, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, nxy, c->d_colorder);
-    }
     hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
     VP_HIP(hipGetLastError());
     // totals are needed on the host to size the pair and brick pools

@@ -5,22 +5,21 @@
 // front-to-back propagate + RGBA16F store; draws serialised in z through a UAV (lightPropogationTex).
 //
 // CDNA4 shape (this file):
-//   * workgroup = 16x16 voxel columns (4 waves, each an 8x8-column tile: the most compact footprint against a
-//     particle's sphere, i.e. the highest lane utilisation in covered slices; a slice store of a wave is eight
-//     64-byte half lines), persistent along the light axis: it walks its MV column zz = z0..z1 carrying the
-//     transmitted light in a register, so the z-order dependency never leaves the chip and the light map is
-//     written once;
-//   * workgroups are dispatched heaviest-column-first (k_col_weight + k_col_rank) to bound the tail;
+//   * unit of work = one wave on an 8x8-column tile of ONE occupied metavoxel (the most compact footprint against a particle's
+//     sphere, i.e. the highest lane utilisation in covered slices; a slice store of a wave is eight 64-byte half lines), claimed
+//     from a counter in z-major order; the light a voxel column has transmitted so far is handed from the unit of one occupied
+//     metavoxel to the unit of the column's next one through a tagged 64-bit word (FillChain below), so the z-order dependency
+//     costs one load and one store per column and metavoxel and the light map is written once;
 //   * per (wave, particle): the column is a line ps(s) = A + s*B in particle space, so coverage is a quadratic
 //     in the slice index; each lane solves it, a DPP OR-reduction merges the per-lane slice masks, and only the
 //     wave-uniform slice range is tested (exact test unchanged: |ps|^2 <= 0.25, Fill.shader:172);
 //   * particle records are wave-uniform -> scalar loads (s_load_dwordx16), matrix elements live in SGPRs;
 //   * per-slice accumulators (density sum, ao max) are register arrays indexed by the uniform slice
 //     (s_set_gpr_idx), no LDS, no scratch;
-//   * the displacement cubemap is pre-expanded to bilinear footprints: one 16-byte load per covered voxel
-//     instead of four texel fetches (gfx950 has no image/sampler hardware).
-// Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernel is limited well before it by VALU issue and by the
-// L2 request rate of the per-voxel footprint gather.
+//   * the displacement cubemap is pre-expanded to bilinear footprints (one 16-byte load per covered voxel instead of four texel
+//     fetches: gfx950 has no image/sampler hardware), or -- 8-bit maps, the reference asset's format -- lives in LDS as bytes.
+// Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernels are limited well before it by VALU issue (k_fill_lds) and by
+// the CU's L1/TA rate of the per-voxel footprint gather (k_fill).
 #include <cstdlib>
 #include <type_traits>
 
@@ -278,9 +277,6 @@ __device__ __forceinline__ void chain_publish(unsigned long long* w, float v, ui
 
 // MODE 0: fused fill (bricks + light map).  MODE 1: slab-local pass: density/ao to scratch, slab transmittance
 // (propagation with T_in = 1) to light_out.
-#ifndef VPFX_FILL_CHAIN
-#define VPFX_FILL_CHAIN 1       // persistent LDS kernel: per-metavoxel units with the light handed on through memory (0: whole-column units)
-#endif
 #ifndef VPFX_FILL_WAVES
 #define VPFX_FILL_WAVES 3      // min waves per SIMD: caps the kernels at 168 VGPRs (without the cap hipcc takes 165-174 and NV = 64 drops to 2 waves)
 #endif
@@ -592,9 +588,8 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restric
 // R8 cube maps (the reference's own asset format): the whole map, 6 (S+2)^2 bytes with the clamp border replicated (99 KB at
 // S = 128), lives in LDS, so the per-voxel footprint gather never leaves the CU -- on the global table that gather, not the
 // arithmetic, is what k_fill waits for (one wave-wide divergent load per covered slice through the CU's single L1/TA path).
-// One PERSISTENT workgroup of 12 waves per CU (3 per SIMD, the same occupancy as k_fill) loads the table once; every wave then
-// pulls 8x8-column tiles from a global work counter, heaviest MV column first (finer-grained than k_fill's 4-wave workgroups: a wave
-// that finishes early starts the next tile instead of idling until its three siblings are done).
+// One PERSISTENT workgroup of 16 waves per CU (4 per SIMD) loads the table once; every wave then pulls (metavoxel, 8x8-column tile)
+// units from a global work counter on its own.
 template <int NV, int MODE, int TAB>
 __global__ void __launch_bounds__(64 * VPFX_FILL_LDS_WAVES)
 k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
@@ -613,19 +608,12 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
         if (item >= nitems) break;
         const int sub = item % TPC;
         const int px = (sub % T8) * 8 + (lane & 7), py = (sub / T8) * 8 + (lane >> 3);
-#if VPFX_FILL_CHAIN
         // unit = (occupied metavoxel, tile), metavoxels z-major (a unit's producer is always claimed before it)
         const int mi = ch.occ_list[item / TPC];
         const int nxy = g.Nx * g.Ny, zz = mi / nxy, col = mi - zz * nxy;
         const int xx = col % g.Nx, yy = col / g.Nx;
         fill_tile<NV, false, MODE, TAB, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap,
                                               p_light_in, p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, zz, zz + 1, ch);
-#else
-        const int col = p_colorder[item / TPC];
-        const int xx = col % g.Nx, yy = col / g.Nx;
-        fill_tile<NV, false, MODE, TAB>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
-                                        p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, g.z0, g.z1);
-#endif
     }
 }
 
@@ -636,7 +624,7 @@ k_fill_finish(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const float* __restri
 {
     constexpr int TW = NV / 16;
     constexpr int TPM = TW * TW;
-    const int col = p_colorder[blockIdx.x / TPM];
+    const int col = blockIdx.x / TPM;
     const int tile = blockIdx.x % TPM;
     const int xx = col % g.Nx, yy = col / g.Nx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -789,13 +777,9 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     if (!granted) { int rc = allow_big_lds(c, kernel, 160 * 1024); if (rc) return rc; granted = true; }
     constexpr int TPC = (NV / 8) * (NV / 8);
     FillChain ch{};
-#if VPFX_FILL_CHAIN
     const int nitems = c->h_meta.occupied * TPC;
     { int rc = chain_begin(c, P, MODE, ch); if (rc) return rc; }
     if (nitems == 0) return VP_OK;
-#else
-    const int nitems = c->g.Nx * c->g.Ny * TPC;
-#endif
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     constexpr int WV = VPFX_FILL_LDS_WAVES;
     const int grid = nitems < WV * c->num_cus ? (nitems + WV - 1) / WV : c->num_cus;   // one persistent workgroup per CU
@@ -913,7 +897,7 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
 {
     FillPtrs P{};
     P.mvPos = c->d_mvPos; P.offsets = c->d_offsets; P.ids = c->d_ids; P.rec = c->d_rec;
-    P.brick_index = c->d_brick_index; P.colorder = c->d_colorder; P.cubequads = c->d_cubequads;
+    P.brick_index = c->d_brick_index; P.colorder = nullptr; P.cubequads = c->d_cubequads;
     P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
     P.light_in = d_light_in; P.light_out = d_light_out;
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;

@@ -110,9 +110,7 @@ struct vp_ctx {
     int* d_ids_tmp = nullptr;     // [pairs_cap]
     int* d_ids = nullptr;         // [pairs_cap]
     size_t pairs_cap = 0;
-    int* d_colorder = nullptr;    // [Nx*Ny] MV columns, heaviest first
     int* d_onecol = nullptr;      // [2] one MV column index (per-metavoxel fill) + the cube-map range flag
-    int* d_colweight = nullptr;   // [Ny*Nx] pairs (+ a per-MV constant) per MV column: the sort key of d_colorder
     DevMeta* d_meta = nullptr;
     void* d_scan_totals = nullptr; // [ceil(N^3 / 1024)] per-tile totals of the two-launch scan
     DevMeta h_meta{};
