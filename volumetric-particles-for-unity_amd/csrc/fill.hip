@@ -20,7 +20,6 @@
 //     fetches: gfx950 has no image/sampler hardware), or -- 8-bit maps, the reference asset's format -- lives in LDS as bytes.
 // Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernels are limited well before it by VALU issue (k_fill_lds) and by
 // the CU's L1/TA rate of the per-voxel footprint gather (k_fill).
-#include <cstdlib>
 #include <type_traits>
 
 #include "vpfx_internal.h"
@@ -37,9 +36,6 @@
 #define VPFX_STR(x) VPFX_STR2(x)
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
-#endif
-#ifndef VPFX_FILL_LDS_SELECT
-#define VPFX_FILL_LDS_SELECT 0   // 1: lanes without a covered voxel read byte 0 (costs a v_cndmask + hazard nops per slice; measured slower)
 #endif
 #ifndef VPFX_FILL_PIPE
 #define VPFX_FILL_PIPE 4      // 2..6; measured at C3: 2 -> 5.33 ms, 3 -> 5.07 (4 waves/SIMD), 4 -> 4.80 (3 waves/SIMD)
@@ -86,9 +82,6 @@ __device__ __forceinline__ void wait_vm_dyn(int i, f32x4& q)
 // slice loop's instructions); with the arrays pinned to fixed registers the update is the two arithmetic instructions themselves, issued
 // inside ONE indexing window with source-0 and destination both relative:  v_add_f32 v[0+s], v[0+s], den ; v_max_i32 v[32+s], v[32+s], net
 // (ao and net are >= 0, so the integer max of the bit patterns is the float max; the exec mask restricts both to the covered lanes).
-#ifndef VPFX_FILL_DIRECT_ACC
-#define VPFX_FILL_DIRECT_ACC 1
-#endif
 // A/B switch for the north_star's "scattered into LDS-resident voxel tiles" (SURVEY section 7): 1 / 2 keep the wave's (density, ao)
 // tile -- CH slices x 64 columns x 2 floats = 16 KB -- in LDS instead of registers and scatter into it particle by particle (1:
 // read + add + write, deterministic order; 2: ds_add_f32, the LDS float atomic); 0 (product) = register arrays.  Global-table
@@ -342,13 +335,9 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 #pragma unroll
             for (int s = 0; s < CH; ++s) { lds_dens[s * 64] = 0.f; lds_ao[s * 64] = 0.f; }
             struct { float* p; __device__ float operator[](int s) const { return p[s * 64]; } } dens{lds_dens}, ao{lds_ao};
-#elif VPFX_FILL_DIRECT_ACC
+#else
             typename AccArr<CH>::type dens, ao;
             AccArr<CH>::clear(dens, ao);                                                 // "clear it"  :178-181
-#else
-            float dens[CH], ao[CH];
-#pragma unroll
-            for (int s = 0; s < CH; ++s) { dens[s] = 0.f; ao[s] = 0.f; }                 // "clear it"  :178-181
 #endif
 
             // Vectorised pre-cull: 64 particles of the MV's list at a time, one per lane, sphere vs. this wave's
@@ -425,7 +414,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         const unsigned off = hit ? qi : 0u;                              // byte offset into the footprint table
                         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
                     } else if constexpr (TAB == 1) {
-                        const unsigned off = VPFX_FILL_LDS_SELECT ? (hit ? qi : lds_base) : qi;   // lanes without a covered voxel all read byte 0 (a broadcast)
+                        const unsigned off = qi;   // every lane reads: any direction addresses inside the table (a select for the lanes without a covered voxel cost more)
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "+1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
                     } else {
@@ -448,12 +437,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 #elif VPFX_FILL_LDS_TILE == 2
                         atomicAdd(lds_dens + s * 64, den);                               // ds_add_f32
                         atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));
-#elif VPFX_FILL_DIRECT_ACC
-                        AccArr<CH>::add_max(dens, ao, s, den, net);                      // :200-201
 #else
-                        dens[s] += den;                                                  // :200
-                        // ao = max(ao, net) (:201); both are >= 0, so the max of the bit patterns is the float max
-                        ao[s] = __int_as_float(max(__float_as_int(ao[s]), __float_as_int(net)));
+                        AccArr<CH>::add_max(dens, ao, s, den, net);                      // :200-201
 #endif
                     }
                 };
@@ -811,15 +796,10 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
     if (c->h_meta.occupied == 0) return VP_OK;
     const dim3 grid(c->h_meta.occupied * TPM);
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
-#if VPFX_FILL_LDS_TILE
-    static const int dbg_lds = 4 * 2 * (NV < 32 ? NV : 32) * 64 * (int)sizeof(float);        // the four waves' (density, ao) tiles
-#else
-    static const int dbg_lds = getenv("VPFX_FILL_LDS") ? atoi(getenv("VPFX_FILL_LDS")) : 0;   // occupancy experiments only
-#endif
-    const int tl = VPFX_FILL_LDS_TILE ? dbg_lds : 0;
+    const int tl = VPFX_FILL_LDS_TILE ? 4 * 2 * (NV < 32 ? NV : 32) * 64 * (int)sizeof(float) : 0;    // A/B variant: the four waves' (density, ao) tiles
     if (mode == 0) {
         if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
-        else       hipLaunchKernelGGL((k_fill<NV, false, 0, true>), grid, block, dbg_lds, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
+        else       hipLaunchKernelGGL((k_fill<NV, false, 0, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
     } else {
         if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
         else       hipLaunchKernelGGL((k_fill<NV, false, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
