@@ -190,9 +190,9 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     }
     const float x0 = floorf(fx), y0 = floorf(fy);
     // EXACT keeps the oracle's fx - floor(fx); the fast path uses v_fract_f32 (identical except that a weight that
-    // would round up to exactly 1.0 is returned as the largest float below 1).  (Taking the index as fx - fract(fx), a full-rate
-    // subtract instead of the half-rate v_floor, and advancing the slice index with adds instead of converting it were measured:
-    // bit-identical bricks, no gain -- the kernel is not bound by those few VALU cycles.)
+    // would round up to exactly 1.0 is returned as the largest float below 1).  (Measured without gain, bit-identical bricks: the
+    // subtract in the fast path too -- it costs two registers more and with them two spills --, the index as fx - fract(fx) instead of
+    // v_floor, the slice index advanced by adds instead of converted.)
     tx = EXACT ? fx - x0 : __builtin_amdgcn_fractf(fx);
     ty = EXACT ? fy - y0 : __builtin_amdgcn_fractf(fy);
     // |sc|, |tc| <= |major|, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
@@ -209,7 +209,8 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
 template <bool EXACT>
 __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
                                            const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
-                                           float d2, float opw, float& den, float& net, float Dk /* D, or D/255 for byte texels */)
+                                           float d2, float opw, float& den, float& net, float Dk /* D, or D/255 for byte texels */,
+                                           float smooth_c1 /* 10/3 in a VGPR: a VOP3 FMA reads one SGPR / no literal */)
 {
     const float a = fmaf(tx, q.z - q.x, q.x), b = fmaf(tx, q.w - q.y, q.y);
     const float raw = fmaf(ty, b - a, a);
@@ -225,8 +226,14 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
         // (x - net) / (0.7 net - net) is x / +0 = +inf -> saturate 1 (density = opacityFactor; 0 / 0 saturates to 0) while
         // 10/3 - (40/3) d2 / 0 would give 0.  (4 d2 - net) * rcp(fma(net, 0.7, -net)) keeps the sign of that zero; it costs 3 % of
         // the kernel, so it is only taken when D == 1 (a wave-uniform integer flag: scalar compare + branch).
-        if (f.d_is_one) t = __builtin_amdgcn_fmed3f(fmaf(d2, 4.0f, -net) * __builtin_amdgcn_rcpf(fmaf(net, 0.7f, -net)), 0.f, 1.f);
-        else            t = __builtin_amdgcn_fmed3f(fmaf(d2 * __builtin_amdgcn_rcpf(net), -13.333333f, 3.3333333f), 0.f, 1.f);
+        // (the saturate rides on the producing instruction's clamp bit; hipcc otherwise spends a v_max_f32 ... clamp after a literal-form FMA)
+        if (f.d_is_one) {
+            const float num = fmaf(d2, 4.0f, -net), rden = __builtin_amdgcn_rcpf(fmaf(net, 0.7f, -net));
+            asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(t) : "v"(num), "v"(rden));
+        } else {
+            const float q = d2 * __builtin_amdgcn_rcpf(net);
+            asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(q), "s"(-13.333333f), "v"(smooth_c1));
+        }
     }
     // :126-127, :130-131: t*t*(3 - 2t) * opacityFactor * (fade ? opacity : 1).  opw = 1.0 exactly when _FadeOutParticles is off.
     // The fast path folds the wave-uniform factors into the cubic's coefficients (t*t) * (3k - 2k t), k = opacityFactor * opw.
@@ -301,6 +308,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
     float prop = (MODE == 0 && p_light_in) ? p_light_in[lmi] : 1.0f;                     // GL.Clear(Color.red) VPR.cs:499
     float one_minus_D = f.one_minus_D;
     asm volatile("" : "+v"(one_minus_D));                                                // keep it in a VGPR (see cube_shade)
+    float smooth_c1 = 3.3333333f;
+    asm volatile("" : "+v"(smooth_c1));
 
     for (int zz = zz_a; zz < zz_b; ++zz) {                                               // z-major = draw order VPR.cs:505
         const int mi = (zz * g.Ny + yy) * g.Nx + xx;
@@ -430,7 +439,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         float4 qf;
                         if constexpr (TAB == 0) qf = make_float4(q[0], q[1], q[2], q[3]);
                         else qf = make_float4((float)q.a, (float)q.b, (float)q.c, (float)q.d);   // bytes 0..255; 1/255 is folded into Dk
-                        cube_shade<EXACT>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk);
+                        cube_shade<EXACT>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
 #if VPFX_FILL_LDS_TILE == 1
                         lds_dens[s * 64] += den;                                         // ds_read_b32, v_add_f32, ds_write_b32
                         atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));   // ds_max_i32
