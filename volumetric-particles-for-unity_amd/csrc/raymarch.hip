@@ -172,8 +172,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     struct Addr { const uint2* p; float wx, wy, wz; int ix, iy, iz; };
     struct Quad { TexelPair t00, t10, t01, t11; };    // [z][y]: texels (x0, x0+1)
     struct QuadG { uint32_t a0, a1, b0, b1, c0, c1, d0, d1; };   // grey: [z0y0], [z0y1], [z1y0], [z1y1] x (x0, x0+1), each lum | dens
-    auto address = [&](int si) -> Addr {
-        const float fi = (float)si;
+    auto address = [&](float fi /* lattice index, an exact integer */) -> Addr {
         const float fx = fmaf(fi, fsx, f0x), fy = fmaf(fi, fsy, f0y), fz = fmaf(fi, fsz, f0z);
         const float x0 = floorf(fx), y0 = floorf(fy), z0 = floorf(fz);
         Addr a;
@@ -253,12 +252,14 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     // so that eight texel-pair loads are in flight.
     const int tSoft = max(tEntry, min(tExit + 1, tCamera + k.soft));
     int si = tExit;
+    float fsi = (float)si;                              // the index as a float, stepped with adds (one conversion per metavoxel, not per sample)
     // (Measured and dropped: issuing the next two samples' eight loads before filtering the current two -- two register sets, 8-16 loads
     // in flight per wave -- 1.49 vs 1.48 ms: loads in flight per wave are not what limits the kernel.)
     // (Grey bricks, measured: four samples per iteration -- 8 loads in flight -- 1.02 ms at 4 waves/SIMD against 1.09 for two, but the
     // two-sample loop fits 5 waves/SIMD: 1.00 ms.)
     for (; si - 1 >= tSoft; si -= 2) {
-        const Addr a0 = address(si), a1 = address(si - 1);
+        const Addr a0 = address(fsi), a1 = address(fsi - 1.0f);
+        fsi -= 2.0f;
         Quad q0, q1;
         if (GREY) {
             u32x4 u0, u1, v0, v1;
@@ -292,7 +293,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
         }
     }
     for (; si >= tEntry; --si) {
-        const Addr a = address(si);
+        const Addr a = address((float)si);
         F4 c;
         if constexpr (GREY) c = filter_grey(fetch_grey(a), a); else c = filter(fetch(a), a);
         const int dc = si - tCamera;
