@@ -3,12 +3,12 @@ import sys, time
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package; load_package()
 from vpfx_amd import scene as S, engine as E
-sc = S.make_scene(sys.argv[1] if len(sys.argv) > 1 else "C3")
+sc = S.make_scene(sys.argv[1] if len(sys.argv) > 1 else "C3", cubemap="r8")     # the bench input
 e = E.Engine(sc.config()); e.set_frame(sc.light_to_world, sc.grid_center)
 fp0, fp = sc.fill_params(), sc.fill_params(); fp.cubemap = None
 cam, rp = sc.camera(), sc.raymarch_params()
 e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp0); e.raymarch(cam, rp)
-n = 10
+n = 50
 t0 = time.perf_counter()
 for _ in range(n):
     e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp); img = e.raymarch(cam, rp)
