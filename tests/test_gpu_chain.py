@@ -82,3 +82,24 @@ def test_many_refills_of_one_context(cubemap):
     g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     g.fill(sc.fill_params())
     np.testing.assert_array_equal(g.read_lightmap(), lm0)
+
+
+def test_tag_range_wraps_after_many_launches_on_a_deep_grid():
+    """tag = launch number x (Nz + 1) + ordinal is 32 bits wide: on a grid 2^20 metavoxels deep the range is used up after 4 095 fills and
+    the hand-off words are cleared (launch_fill_lds_variant / chain_begin).  The fill must be the same before, at and after the wrap."""
+    sc = S.make_scene("deep", dims=(4, 16, 60, 32, 24), cubemap="r8", seed=3)
+    sc.N = (1, 1, 1 << 20)
+    sc.particles["position"][:, :2] *= 0.1                         # keep the particles inside the one column ...
+    sc.particles["position"][:, 2] *= 8.0                          # ... and spread them over a few dozen metavoxels along the light axis
+    o, g = engines(sc)
+    cnt = o.bin_counts()
+    assert (cnt > 0).sum() >= 6
+    check(o, g, False)
+    lm0 = g.read_lightmap()
+    zz0 = int(np.nonzero(cnt[:, 0, 0])[0][-1])                     # the column's last occupied metavoxel
+    b0 = g.read_brick(0, 0, zz0).copy()
+    for i in range(4200):
+        g.fill(sc.fill_params())
+        if i in (4090, 4093, 4094, 4095, 4096, 4199):
+            np.testing.assert_array_equal(g.read_lightmap(), lm0)
+            np.testing.assert_array_equal(g.read_brick(0, 0, zz0), b0)
