@@ -33,6 +33,14 @@ from vpfx_amd import engine as E, parallel as PAR, scene as S  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def baseline_metric():
+    """BASELINE.json's metric string verbatim (the file travels with the repo); the same text if it is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "Mvoxels/s filled + Msamples/s raymarched, 32\u00b3\u00d732\u00b3 grid @1080p"
+
+
 def kernel_sources_sha():
     """Fingerprint of the kernel sources: profiles/traffic_<cfg>.json records the one it was measured on, and bench.py only
     reports that PMC measurement as `roofline.traffic` while it still matches (a stale number is worse than null)."""
@@ -281,7 +289,7 @@ def main():
         # N > 1: the sharded frame against the single-GPU frame rendered on this rank before the timed region
         shard_err = float((image - ref_image).abs().max().item()) if (ref_image is not None and image is not None) else None
         out = {
-            "metric": "Mvoxels/s filled + Msamples/s raymarched, 32^3x32^3 grid @1080p",
+            "metric": baseline_metric(),
             "value": (voxels + samples) / (dt / args.steps) / 1e6,
             "unit": "M(voxels+samples)/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
