@@ -52,6 +52,14 @@ def test_fill_kernel_resources():
     assert body.count("s_set_gpr_idx_on") >= 8
     assert body.count("v_cndmask") < 200            # a compare/select lowering of the 32-entry arrays would be thousands
     assert body.count("v_cubeid_f32") >= 4
+    # chained fill: the light hand-off is ONE agent-scope relaxed atomic load (polled) and ONE store of a 64-bit word per column and
+    # metavoxel -- and nothing else: no fence may sneak in (a release at agent scope would write back the whole L2 per unit)
+    for kern in ("k_fill_ldsILi32ELi0ELi1E", "k_fillILi32ELb0ELi0ELb1E"):
+        b = asm[asm.index(kern):]
+        b = b[:b.index("s_endpgm")]
+        assert re.search(r"global_load_dwordx2 v\[\d+:\d+\], v\[\d+:\d+\], off sc1", b), kern
+        assert re.search(r"global_store_dwordx2 v\[\d+:\d+\], v\[\d+:\d+\], off sc1", b), kern
+        assert "buffer_wbl2" not in b and "buffer_inv" not in b, kern
 
 
 def test_raymarch_kernel_resources():
