@@ -140,9 +140,13 @@ def one_case(seed):
         rq.flags = abi.VP_RM_QUANTIZE_UNORM8
         iq_o, iq_g = o.raymarch(cam, rq), g.raymarch(cam, rq)
         # re-quantising after every blend is discontinuous: a 1e-7 difference in front of a rounding threshold flips one 8-bit
-        # step, a later blend can turn that into two; anything beyond that, or more than a few such pixels, is a real mismatch
+        # step, a later blend can turn that into two -- and when the flipped value is an alpha next to saturation (253 vs 254 of 255),
+        # every later UNDER contribution is scaled by 1 - alpha = 2/255 instead of 1/255 and a colour channel ends up three or four
+        # steps off (seed 200787: one pixel of 6144, unquantised images equal to 6e-8).  More than that, or more than a few such
+        # pixels, is a real mismatch.
         dq = np.abs(iq_o - iq_g).max(axis=-1)
-        assert float(dq.max()) <= 2.01 / 255 and int((dq > 1.01 / 255).sum()) <= 3, f"unorm8 emulation {dq.max() * 255:.2f} steps"
+        assert float(dq.max()) <= 4.01 / 255 and int((dq > 2.01 / 255).sum()) <= 1 and int((dq > 1.01 / 255).sum()) <= 3, \
+            f"unorm8 emulation {dq.max() * 255:.2f} steps"
     # a second frame on the SAME contexts: other particles, other camera -- stale bins / bricks / light map would show here
     if seed % 2 == 0 and len(sc.particles) > 4:
         keep = rng.random(len(sc.particles)) < 0.6
