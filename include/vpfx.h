@@ -59,7 +59,9 @@ typedef struct vp_config {
     int32_t exact_math;       /* 1: IEEE divisions in the fill kernel (bit-parity test builds)     */
     int32_t no_early_out;     /* 1: the ray-march never stops early (sample-count parity tests)    */
     int32_t reserved[3];      /* 0.  (Measurement switches: [0] = 1 keeps an R8 cube map out of LDS,
-                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey.)       */
+                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey.  Test hook:
+                                 [2] = 1 makes the fill's units wait for a light hand-off that never comes,
+                                 to exercise the watchdog's error path.)                              */
 } vp_config;
 
 /* Byte layout of one caller-side particle record (ParticleSystem.Particle[], VPR.cs:412-413).

@@ -103,3 +103,19 @@ def test_tag_range_wraps_after_many_launches_on_a_deep_grid():
         if i in (4090, 4093, 4094, 4095, 4096, 4199):
             np.testing.assert_array_equal(g.read_lightmap(), lm0)
             np.testing.assert_array_equal(g.read_brick(0, 0, zz0), b0)
+
+
+def test_watchdog_reports_a_hand_off_that_never_arrives():
+    """vp_config.reserved[2] = 1 (test hook): units await tags nobody writes and give up after a few polls.  The fill then completes --
+    no hung GPU -- and the next synchronising call returns an error; the context stays usable."""
+    sc = S.make_scene("C1", cubemap="r8")
+    cfg = sc.config()
+    cfg.reserved[2] = 1
+    g = E.Engine(cfg)
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    g.fill(sc.fill_params())
+    with pytest.raises(Exception, match="hand-off"):
+        g.sync()
+    g.sync()                                                       # the flag is consumed: the context keeps working
+    assert g.stats()["occupied_mv"] > 0

@@ -38,6 +38,18 @@ int ensure_device(vp_ctx* c)
     return VP_OK;
 }
 
+// Stream sync of the host-facing entry points + the chained fill's watchdog flag (a unit that waited ~seconds for its column's light
+// sets it and carries on with whatever it read: an error the caller sees instead of a hung GPU).
+int stream_sync(vp_ctx* c)
+{
+    VP_HIP(hipStreamSynchronize(c->stream));
+    if (c->h_chain_err && *(volatile int*)c->h_chain_err) {
+        *(volatile int*)c->h_chain_err = 0;
+        return vp_fail(c, VP_ERR_HIP, "fill: a light hand-off between metavoxel units timed out (results of the last fill are invalid)");
+    }
+    return VP_OK;
+}
+
 size_t lightmap_elems(const vp_ctx* c) { return (size_t)c->g.Nx * c->g.nv * c->g.Ny * c->g.nv; }
 size_t image_elems(const vp_ctx* c) { return (size_t)c->cfg.width * c->cfg.height * 4; }
 size_t nv3(const vp_ctx* c) { return (size_t)c->g.nv * c->g.nv * c->g.nv; }
@@ -123,7 +135,7 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
     if (p->light_depth_map) {
         if (!c->d_depthmap) { int rc = dev_alloc(c, &c->d_depthmap, lightmap_elems(c)); if (rc) return rc; }
         VP_HIP(hipMemcpyAsync(c->d_depthmap, p->light_depth_map, lightmap_elems(c) * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        VP_HIP(hipStreamSynchronize(c->stream));
+        { int rcs = stream_sync(c); if (rcs) return rcs; }
         c->have_depthmap = true;
     } else if (c->n_occluders > 0) {
         // no map given but occluder boxes are set: render the light depth map on the GPU (VPR.cs:184)
@@ -226,6 +238,9 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
         (rc = dev_alloc(c, &c->d_cam_rows, 12)) || (rc = dev_alloc(c, &c->d_tile_order, 2 * ((size_t)rm_num_super_tiles(cfg->width, cfg->height) + 8))))
         return fail(rc);
+    if (hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->d_chain_err, c->h_chain_err, 0) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(VP_ERR_HIP); }
+    *c->h_chain_err = 0;
     if (hipMemset(c->d_chain, 0, lightmap_elems(c) * sizeof(unsigned long long)) != hipSuccess) { c->err = "hipMemset failed"; return fail(VP_ERR_HIP); }
     for (int s = 0; s < 4; ++s)
         for (int j = 0; j < 2; ++j)
@@ -243,6 +258,7 @@ VP_EXPORT void vp_destroy(vp_ctx* c)
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
                    c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples};
     for (void* p : dev) if (p) (void)hipFree(p);
+    if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
     free(c->h_mvPos); free(c->h_rank);
     delete c;
@@ -278,7 +294,7 @@ VP_EXPORT int vp_sync(vp_ctx* c)
 {
     if (!c) return VP_ERR_BAD_ARG;
     int rc = ensure_device(c); if (rc) return rc;
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     return VP_OK;
 }
 
@@ -291,7 +307,7 @@ VP_EXPORT int vp_set_frame(vp_ctx* c, const float light_to_world[16], const floa
     memcpy(c->gc, grid_center, sizeof c->gc);
     hl_build_grid(c);
     VP_HIP(hipMemcpyAsync(c->d_mvPos, c->h_mvPos, c->n3 * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     c->have_frame = true;
     c->binned = c->filled = c->local_done = false;
     return VP_OK;
@@ -331,7 +347,7 @@ VP_EXPORT int vp_upload_particles(vp_ctx* c, const void* particles, int32_t coun
     if (count > 0) {
         VP_HIP(hipMemcpyAsync(c->d_raw, particles, bytes, hipMemcpyHostToDevice, c->stream));
         rc = launch_extract(c); if (rc) return rc;
-        VP_HIP(hipStreamSynchronize(c->stream));               // caller's array is not retained past return
+        { int rcs = stream_sync(c); if (rcs) return rcs; }               // caller's array is not retained past return
     }
     c->have_particles = true;
     c->binned = c->filled = c->local_done = false;
@@ -440,7 +456,7 @@ VP_EXPORT int vp_render_metavoxel(vp_ctx* c, const vp_camera* cam, const vp_raym
     const size_t mi = ((size_t)zz * g.Ny + yy) * g.Nx + xx;
     int bi = -1;
     VP_HIP(hipMemcpyAsync(&bi, c->d_brick_index + mi, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     if (bi < 0) return VP_OK;                                    // empty / not owned: never submitted (VPR.cs:674, 703)
     RmConsts k;
     hl_build_rm_consts(c, cam, rp, &k);
@@ -468,7 +484,7 @@ VP_EXPORT int vp_read_particles_rt(vp_ctx* c, float* rgba_out)
     if (!rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_read_particles_rt: null output");
     int rc = ensure_device(c); if (rc) return rc;
     VP_HIP(hipMemcpyAsync(rgba_out, c->d_image, image_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     return VP_OK;
 }
 
@@ -529,7 +545,7 @@ VP_EXPORT int vp_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_par
     if (!rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch: null output");
     int rc = vp_raymarch_device(c, cam, rp, c->d_image); if (rc) return rc;
     VP_HIP(hipMemcpyAsync(rgba_out, c->d_image, image_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     return VP_OK;
 }
 
@@ -602,7 +618,7 @@ VP_EXPORT int vp_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n)
     }
     if (n > 0) {
         VP_HIP(hipMemcpyAsync(c->d_occluders, boxes, (size_t)n * sizeof(vp_obb), hipMemcpyHostToDevice, c->stream));
-        VP_HIP(hipStreamSynchronize(c->stream));
+        { int rcs = stream_sync(c); if (rcs) return rcs; }
     }
     c->n_occluders = n;
     return VP_OK;
@@ -660,7 +676,7 @@ VP_EXPORT int vp_read_bincounts(vp_ctx* c, int32_t* counts)
     if (!counts) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
     if (!c->binned) return vp_fail(c, VP_ERR_STATE, "vp_read_bincounts before vp_bin");
     int rc = ensure_device(c); if (rc) return rc;
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     VP_HIP(hipMemcpy(counts, c->d_count, c->n3 * sizeof(int), hipMemcpyDeviceToHost));
     return VP_OK;
 }
@@ -673,7 +689,7 @@ VP_EXPORT int vp_read_binlist(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, int
     const GridConsts& g = c->g;
     if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
     int rc = ensure_device(c); if (rc) return rc;
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     const size_t mi = ((size_t)zz * g.Ny + yy) * g.Nx + xx;
     int off[2];
     VP_HIP(hipMemcpy(off, c->d_offsets + mi, 2 * sizeof(int), hipMemcpyDeviceToHost));
@@ -691,7 +707,7 @@ VP_EXPORT int vp_read_brick(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, uint1
     const GridConsts& g = c->g;
     if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
     int rc = ensure_device(c); if (rc) return rc;
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     const size_t mi = ((size_t)zz * g.Ny + yy) * g.Nx + xx;
     int bi = -1;
     VP_HIP(hipMemcpy(&bi, c->d_brick_index + mi, sizeof(int), hipMemcpyDeviceToHost));
@@ -723,7 +739,7 @@ VP_EXPORT int vp_read_lightmap(vp_ctx* c, float* out)
     if (!out) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
     if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_read_lightmap before vp_fill");
     int rc = ensure_device(c); if (rc) return rc;
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     VP_HIP(hipMemcpy(out, c->d_lightmap, lightmap_elems(c) * sizeof(float), hipMemcpyDeviceToHost));
     return VP_OK;
 }
@@ -744,7 +760,7 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
     st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));      // pool as allocated (grey bricks use the first half of it)
     st->brick_bytes_per_voxel = 8;
     st->brick_format = c->bricks_grey ? VP_BRICKS_GREY_ZPAIR : VP_BRICKS_RGBA16F;     // storage of the bricks as last filled
-    VP_HIP(hipStreamSynchronize(c->stream));
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
     unsigned long long s = 0;
     VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));
     st->samples = (int64_t)s;

@@ -260,11 +260,16 @@ struct FillChain {
     const int* colcount;          // [nxy]
     const int* occ_list;          // occupied MVs of the slab, z-major
     uint32_t tag_base;            // launch sequence number x (Nz + 1): tags of different launches never collide
+    int* error;                   // host-mapped watchdog flag
+    uint32_t spin_limit;          // polls before a unit gives up (VPFX_CHAIN_SPIN_LIMIT)
+    uint32_t wait_bias;           // 0; the test hook adds an offset to the awaited tag so that it never arrives
 };
-__device__ __forceinline__ float chain_wait(const unsigned long long* w, uint32_t tag)
+#define VPFX_CHAIN_SPIN_LIMIT (1u << 22)       // x (s_sleep 8 = 512 cycles + a memory round trip): seconds; a real wait is microseconds
+__device__ __forceinline__ float chain_wait(const unsigned long long* w, uint32_t tag, int* error, uint32_t spin_limit)
 {
     unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((uint32_t)(v >> 32) != tag) {
+    for (unsigned spins = 0; (uint32_t)(v >> 32) != tag; ++spins) {
+        if (spins > spin_limit) { *error = 1; break; }        // never seen; reported at the caller's next sync instead of hanging the GPU
         __builtin_amdgcn_s_sleep(8);
         v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -498,7 +503,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 
             if (CHAIN && c0 == 0) {
                 // the light that reaches this metavoxel: what the column's previous occupied metavoxel handed on (its unit was claimed earlier)
-                if (ord > 0) prop = chain_wait(ch.words + lmi, ch.tag_base + (uint32_t)ord);
+                if (ord > 0) prop = chain_wait(ch.words + lmi, ch.tag_base + (uint32_t)ord + ch.wait_bias, ch.error, ch.spin_limit);
                 T = (zz == 0) ? f.init_light : prop;                                     // :224
                 prop = T;
             }
@@ -756,7 +761,10 @@ int chain_begin(vp_ctx* c, const FillPtrs& P, int mode, FillChain& ch)
         VP_HIP(hipMemsetAsync(c->d_chain, 0, lm * sizeof(unsigned long long), c->stream));
         c->chain_seq = 0;
     }
-    ch.words = c->d_chain; ch.ord = c->d_ord; ch.colcount = c->d_colcount; ch.occ_list = c->d_occ_list;
+    ch.words = c->d_chain; ch.ord = c->d_ord; ch.colcount = c->d_colcount; ch.occ_list = c->d_occ_list; ch.error = c->d_chain_err;
+    const bool hook = c->cfg.reserved[2] == VPFX_CFG_TEST_CHAIN_TIMEOUT;
+    ch.spin_limit = hook ? 64u : VPFX_CHAIN_SPIN_LIMIT;
+    ch.wait_bias = hook ? 0x40000000u : 0u;
     ch.tag_base = c->chain_seq * span;
     ++c->chain_seq;
     return VP_OK;

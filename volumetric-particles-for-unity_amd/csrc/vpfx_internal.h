@@ -15,6 +15,8 @@
 #define VPFX_CFG_NO_LDS_CUBEMAP 1
 // vp_config.reserved[1]: 1 keeps RGBA16F bricks when the ambient colour is grey (A/B against the luminance|density format)
 #define VPFX_CFG_NO_GREY_BRICKS 1
+// vp_config.reserved[2]: test hook -- the chained fill awaits tags nobody writes and gives up after a few polls (watchdog error path)
+#define VPFX_CFG_TEST_CHAIN_TIMEOUT 1
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel-constant PODs (passed by value as kernel arguments -> SGPRs / kernarg segment)
@@ -132,6 +134,8 @@ struct vp_ctx {
     int* d_colcount = nullptr;    // [nxy] occupied MVs per column (owned slab)
     unsigned long long* d_chain = nullptr;   // [LH][LW] light hand-off words of the chained fill: tag << 32 | float bits     (fill.hip)
     uint32_t chain_seq = 0;       // fill launches since the hand-off words were last cleared
+    int* h_chain_err = nullptr;   // pinned + mapped: set by a fill unit whose hand-off word never arrived (watchdog, fill.hip); read at every sync
+    int* d_chain_err = nullptr;   // the device view of it
     int num_cus = 0;
     float* d_depthmap = nullptr;
     bool have_depthmap = false;
