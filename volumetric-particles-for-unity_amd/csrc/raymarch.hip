@@ -431,10 +431,10 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #define VPFX_RM_WAVES_PARTIAL 3   // partial images + flag paths (debug views of a slab): the one combination that needs > 128 VGPRs
 #endif
 #ifndef VPFX_RM_WAVES_GREY
-#define VPFX_RM_WAVES_GREY 5      // the plain grey-brick kernel needs 93 VGPRs: 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3; the slab variant would spill 2)
+#define VPFX_RM_WAVES_GREY 5      // the grey-brick kernels without flag paths need 95 VGPRs (whole grid and slab): 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3)
 #endif
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY>
-__global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : (GREY && !PARTIAL && !FLAGS) ? VPFX_RM_WAVES_GREY : VPFX_RM_WAVES)
+__global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : (GREY && !FLAGS) ? VPFX_RM_WAVES_GREY : VPFX_RM_WAVES)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
@@ -466,7 +466,11 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
 
     const RayCtx R = ray_setup(k, col, row, scene_depth);
 
-    F4 dstA{0.f, 0.f, 0.f, 0.f}, dstB{0.f, 0.f, 0.f, 0.f};                                 // OnPreRender clear  VPR.cs:171
+    // ONE accumulator: a slab kernel (PARTIAL) composites its phase-A slabs, stores that image when the first phase-B slab comes up and
+    // starts over (two live images cost 4 registers that the 5-waves/SIMD budget does not have)
+    F4 dst{0.f, 0.f, 0.f, 0.f};                                                            // OnPreRender clear  VPR.cs:171
+    bool storedA = false;
+    const size_t pi = (size_t)row * k.W + col;
     int nsamp = 0;
 
     // ray vs. the owned part of the grid
@@ -513,7 +517,12 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         if (!(ta <= tb)) continue;
         const bool phaseA = zz <= k.zB;                                                    // VPR.cs:667 vs :697
         const bool over = FLAGS && phaseA;                                                 // literal OVER, cells far -> near
-        F4 d = (PARTIAL && !phaseA) ? dstB : dstA;        // by value (written back below): a selected reference would put both images on the stack
+        if (PARTIAL && !phaseA && !storedA) {
+            img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+            dst = F4{0.f, 0.f, 0.f, 0.f};
+            storedA = true;
+        }
+        F4 d = dst;
         const int* occ = brick_index + zz * nxy;
         int last = over ? 0x7fffffff : -1;
         // Walk of the (x,y) cells the ray crosses inside this slab, t in [ta, tb]: an integer DDA -- the cell index is stepped
@@ -603,13 +612,16 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         }
         // saturated: everything farther along the ray is multiplied by (1 - dst.a) == 0.  (A saturated phase-A image of a slab
         // also hides the slab's own phase-B image, which is composited behind it.)
-        if (PARTIAL && !phaseA) dstB = d; else dstA = d;
+        dst = d;
         if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
     }
 
-    const size_t pi = (size_t)row * k.W + col;
-    img_over[pi] = make_float4(dstA.x, dstA.y, dstA.z, dstA.w);
-    if (PARTIAL) img_under[pi] = make_float4(dstB.x, dstB.y, dstB.z, dstB.w);
+    if (PARTIAL && storedA) {
+        img_under[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+    } else {
+        img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+        if (PARTIAL) img_under[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
 }
 
