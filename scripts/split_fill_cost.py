@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package; load_package()
 from vpfx_amd import scene as S, engine as E
-sc = S.make_scene(sys.argv[1] if len(sys.argv) > 1 else "C3")
+sc = S.make_scene(sys.argv[1] if len(sys.argv) > 1 else "C3", cubemap="r8")
 g = E.Engine(sc.config())
 g.set_frame(sc.light_to_world, sc.grid_center)
 g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
