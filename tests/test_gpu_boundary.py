@@ -244,3 +244,20 @@ def test_manager_first_frame_always_fills():
     m2 = _manager(sc)
     ref = m2.OnPostRender(0, sc.particles, sc.layout, sc.camera())
     np.testing.assert_array_equal(img, ref)
+
+
+def test_displacement_scale_one_takes_the_bit_exact_kernels():
+    """Fuzz finding (seeds 404209 / 407542 / 409081 of scripts/fuzz_parity.py): with displacement scale exactly 1 the reference's smoothstep
+    jumps at net displacement 0, so reciprocal-based texture coordinates flipped a voxel now and then.  Such fills run the EXACT kernels:
+    bricks bit-identical to the oracle in default-math contexts too, white-noise byte map or float map."""
+    rng = np.random.default_rng(404209)
+    for fmt in ("r8", "f32"):
+        sc = S.make_scene("d1", dims=(2, 32, 600, 64, 48), fade=1)
+        cube = rng.integers(0, 256, size=(6, 128, 128), dtype=np.uint8)
+        sc.cubemap = cube if fmt == "r8" else np.ascontiguousarray(cube.astype(np.float32) / np.float32(255.0))
+        sc.displacement_scale = 1.0
+        o, g = both(sc)
+        cnt = o.bin_counts()
+        for zz, yy, xx in zip(*np.nonzero(cnt)):
+            assert np.array_equal(o.read_brick(xx, yy, zz).view(np.uint16), g.read_brick(xx, yy, zz).view(np.uint16)), (fmt, xx, yy, zz)
+        np.testing.assert_array_equal(o.read_lightmap(), g.read_lightmap())

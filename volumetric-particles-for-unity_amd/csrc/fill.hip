@@ -225,7 +225,9 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
         // needs the quotient form: displacement scale exactly 1 makes net == 0 on a zero texel, where the reference's
         // (x - net) / (0.7 net - net) is x / +0 = +inf -> saturate 1 (density = opacityFactor; 0 / 0 saturates to 0) while
         // 10/3 - (40/3) d2 / 0 would give 0.  (4 d2 - net) * rcp(fma(net, 0.7, -net)) keeps the sign of that zero; it costs 3 % of
-        // the kernel, so it is only taken when D == 1 (a wave-uniform integer flag: scalar compare + branch).
+        // the kernel, so it is only taken when D == 1 (a wave-uniform integer flag: scalar compare + branch).  (launch_fill now sends D == 1
+        // fills to the EXACT kernels altogether -- the in-face coordinates have to be exact there as well --, so this branch is a safety net;
+        // without it the default path measured 1 % SLOWER, an artefact of instruction scheduling.)
         // (the saturate rides on the producing instruction's clamp bit; hipcc otherwise spends a v_max_f32 ... clamp after a literal-form FMA)
         if (f.d_is_one) {
             const float num = fmaf(d2, 4.0f, -net), rden = __builtin_amdgcn_rcpf(fmaf(net, 0.7f, -net));
@@ -870,7 +872,7 @@ int launch_fill_one(vp_ctx* c, int xx, int yy, int zz)
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
     GridConsts g = c->g;
     g.z0 = zz; g.z1 = zz + 1;
-    const bool exact = c->cfg.exact_math == 1;
+    const bool exact = c->cfg.exact_math == 1 || c->fc.d_is_one != 0;      // see launch_fill
     const dim3 block(256);
 #define VPFX_FILL_ONE(NV)                                                                                            \
     do {                                                                                                              \
@@ -898,7 +900,11 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
     P.light_in = d_light_in; P.light_out = d_light_out;
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
-    const bool exact = c->cfg.exact_math == 1;        // IEEE divisions everywhere (parity builds)
+    // IEEE divisions everywhere: parity builds -- and a displacement scale of exactly 1, where net displacement == texel and the reference's
+    // smoothstep(net, 0.7 net, x) jumps at net == 0 (x / +0 -> 1, but 0 for any net > 0): whether a bilinear weight is EXACTLY 0 then decides
+    // between no density and full density, so reciprocal-based in-face coordinates flip a voxel now and then (fuzz-found: three scenes in
+    // 14 000 with white-noise maps).  Those fills take the bit-exact kernels (about twice the time).
+    const bool exact = c->cfg.exact_math == 1 || c->fc.d_is_one != 0;
     // R8 cube map resident as a byte table that fits LDS: the persistent LDS kernel (default math only; EXACT keeps the f32 table)
     const bool lds = mode != 2 && !exact && c->cube_u8_S > 0 && c->cube_u8_S == c->cubeS && c->cfg.reserved[0] != VPFX_CFG_NO_LDS_CUBEMAP;
     const int evi = mode == 2 ? 3 : 1;
