@@ -105,7 +105,7 @@ def cpu_baseline(sc, threads=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: >= 1 s of timed region at ~5 ms per step)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 1 s of timed region at ~5 ms per step)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="scene name from vpfx_amd.scene.CONFIGS (default: the metric's config)")
     ap.add_argument("--cubemap", default="r8", choices=["r8", "f32"],
