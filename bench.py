@@ -112,6 +112,8 @@ def main():
                     help="displacement cube map texel format: r8 = 8-bit like the reference's asset (LDS-resident in k_fill), f32 = float texels")
     ap.add_argument("--no-lds-cubemap", action="store_true", help="A/B: keep an R8 cube map on the global f32 footprint table")
     ap.add_argument("--no-grey", action="store_true", help="A/B: keep RGBA16F bricks although the ambient colour is grey")
+    ap.add_argument("--displacement-scale", type=float, default=None,
+                    help="override the scene's _DisplacementScale (default 0.7, scene:9016); 1.0 = the slider's maximum (smoothstep jump at net displacement 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
@@ -140,6 +142,8 @@ def main():
             dist.init_process_group(args.backend)
 
     sc = S.make_scene(args.config, cubemap=args.cubemap)
+    if args.displacement_scale is not None:
+        sc.displacement_scale = float(args.displacement_scale)
     weights, fill_w, rm_w, whole_occupied = None, None, None, None
     if world > 1:
         # every rank computes the same (particle, MV)-pair histogram along the light axis (balanced slabs) and the

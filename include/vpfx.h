@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define VPFX_ABI_VERSION 2   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view */
+#define VPFX_ABI_VERSION 3   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
+                                3: vp_config device list (multi-GPU fan-out inside the library, RCCL), VP_ERR_RCCL, Unity plugin entry points */
 
 typedef enum vp_status {
     VP_OK = 0,
@@ -41,7 +42,8 @@ typedef enum vp_status {
     VP_ERR_OOM = -3,         /* device or host allocation failed                                */
     VP_ERR_STATE = -4,       /* call order violated (e.g. raymarch before fill)                 */
     VP_ERR_NO_DEVICE = -5,   /* no HIP device visible (there is no CPU fallback)                */
-    VP_ERR_UNSUPPORTED = -6  /* configuration outside what the kernels are built for            */
+    VP_ERR_UNSUPPORTED = -6, /* configuration outside what the kernels are built for            */
+    VP_ERR_RCCL = -7         /* librccl missing, or an RCCL call failed; see vp_last_error      */
 } vp_status;
 
 typedef struct vp_ctx vp_ctx;
@@ -59,10 +61,37 @@ typedef struct vp_config {
     int32_t exact_math;       /* 1: IEEE divisions in the fill kernel (bit-parity test builds)     */
     int32_t no_early_out;     /* 1: the ray-march never stops early (sample-count parity tests)    */
     int32_t reserved[3];      /* 0.  (Measurement switches: [0] = 1 keeps an R8 cube map out of LDS,
-                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey.  Test hook:
-                                 [2] = 1 makes the fill's units wait for a light hand-off that never comes,
-                                 to exercise the watchdog's error path.)                              */
+                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey; [2] must be 0.
+                                 Any other value is refused with VP_ERR_BAD_ARG.)                    */
+    /* ---- ABI 3: multi-GPU fan-out INSIDE the library ("device list", "multi-GPU fan-out is internal").
+     * num_devices <= 1 and world_size == 0: one GPU (`device`), everything above.  Otherwise the context is a FAN-OUT context: the grid
+     * is cut into world_size contiguous light-axis slabs (cost-balanced, see vp_rebalance), slab r lives on the GPU of rank r, and
+     * vp_set_frame / vp_bin / vp_fill / vp_raymarch stay the only calls the host makes: the library runs one host thread, one HIP stream
+     * and one RCCL rank per local device, all-gathers the slab transmittance maps (fill), hands the saturation of the slabs in front to
+     * the slabs behind and exchanges + blends the partial images (ray-march) over RCCL / xGMI.  The image is delivered on rank 0.
+     *   one process drives all GPUs (the C# / C host):  num_devices = N, devices[] = the HIP ordinals, world_size = 0
+     *   one process per GPU (torchrun-style launch):    num_devices = 1, devices[0] = local GPU, world_size = N, first_rank = rank,
+     *                                                    rccl_unique_id = the 128 bytes vp_rccl_unique_id() returned on rank 0 */
+    int32_t num_devices;      /* local GPUs this process drives (0 = 1 = `device` alone unless world_size > 1)       */
+    int32_t devices[8];       /* HIP ordinals, slab order; entries may only repeat with VP_MULTI_PEER_COPY            */
+    int32_t world_size;       /* total ranks (= slabs) of a multi-process job; 0 = num_devices                        */
+    int32_t first_rank;       /* rank of devices[0] (ranks of one process are consecutive)                            */
+    int32_t multi_flags;      /* VP_MULTI_* bits                                                                       */
+    int32_t rm_groups;        /* saturation hand-off: the slabs, front to back, form this many groups; a group's slabs march
+                                 concurrently knowing the opacity of every earlier group.  1 = no hand-off, world_size = a fully
+                                 serial chain (fewest samples, longest latency), 0 = default (2 from 4 ranks on)     */
+    uint8_t rccl_unique_id[128];
 } vp_config;
+
+#define VP_MAX_LOCAL_DEVICES 8
+#define VP_MAX_RANKS 16
+/* vp_config.multi_flags */
+#define VP_MULTI_PEER_COPY           1  /* TEST HOOK: no RCCL; every exchange is a device-to-device copy between the local contexts (all ranks
+                                           must be local).  devices[] may then repeat, e.g. {0,0,0,0}: four slabs on one GPU                */
+#define VP_MULTI_EXCHANGE_ALL_GATHER 2  /* image exchange = ONE all-gather of whole partial images, blended on the display rank (the north-star
+                                           form); default = all-to-all of screen pieces, sharded blend, gather (8x less xGMI traffic)        */
+#define VP_MULTI_UNIFORM_SLABS       4  /* equal-thickness slabs; default: balanced from the work histograms                                  */
+#define VP_MULTI_FORCE               8  /* take the fan-out path (threads, RCCL communicator, collectives) even with one rank                 */
 
 /* Byte layout of one caller-side particle record (ParticleSystem.Particle[], VPR.cs:412-413).
  * Offsets are explicit because the managed struct layout is Unity-version specific. */
@@ -246,7 +275,37 @@ int  vp_set_occluders(vp_ctx* ctx, const vp_obb* boxes, int32_t n);
 int  vp_render_light_depth(vp_ctx* ctx, float light_near, float light_far, float light_cam_distance, float* out /* [(Ny*nv)][(Nx*nv)] */);
 int  vp_render_scene_depth(vp_ctx* ctx, const vp_camera* cam, float* out /* [H][W] linear eye depth, 3e38 = nothing */);
 
-/* ---- multi-GPU (one context per GPU, each owning a contiguous zz slab) ---------------------- */
+/* ---- multi-GPU inside the library (fan-out contexts, vp_config.num_devices / world_size) ---------------------- */
+typedef struct vp_multi_info {
+    int32_t world_size, num_local, first_rank;
+    int32_t rccl_ranks;           /* ncclCommCount of the communicator; 0 with VP_MULTI_PEER_COPY                              */
+    int32_t exchange;             /* 0 tiles (all-to-all + gather), 1 all-gather                                               */
+    int32_t rm_groups;
+    int32_t slab_cuts[VP_MAX_RANKS + 1];   /* slab r = zz in [slab_cuts[r], slab_cuts[r + 1])                                  */
+    int32_t chain[VP_MAX_RANKS];  /* ranks front to back as the last vp_raymarch composited them                               */
+    int32_t group_of[VP_MAX_RANKS];        /* hand-off group of every rank in that frame                                       */
+    int64_t samples[VP_MAX_RANKS];         /* lattice samples executed per LOCAL rank in the last vp_raymarch (0 for remote ones) */
+    float   stage_ms[VP_MAX_RANKS][4];     /* per LOCAL rank: bin, fill (local pass), ray-march, fill finish kernel times       */
+    float   exchange_ms[4];       /* rank-0-of-this-process stream time: tau all-gather, saturation hand-off, image exchange + blend, - */
+} vp_multi_info;
+int  vp_get_multi_info(vp_ctx* ctx, vp_multi_info* out);
+/* Re-cut the slabs at the next vp_bin*: light-axis slices are weighted with this frame's (particle, metavoxel) pairs (fill) and the
+ * samples the last vp_raymarch executed in them (ray-march), both measured on the GPUs; collective over all ranks. */
+int  vp_rebalance(vp_ctx* ctx);
+/* 128 bytes identifying a new RCCL communicator (ncclGetUniqueId): call on ONE process, hand the bytes to every process of the job
+ * (any transport: MPI, a TCP store, a file) and pass them in vp_config.rccl_unique_id. */
+int  vp_rccl_unique_id(uint8_t out[128]);
+/* The slab cut itself (host-only, no GPU needed): fill_ms[z], rm_ms[z] = estimated milliseconds per light-axis slice; the frame waits for
+ * the slowest slab in the fill and, per hand-off group, in the ray-march.  cuts_out[world + 1]. */
+int  vp_plan_slabs(int32_t nz, int32_t world, const double* fill_ms, const double* rm_ms, int32_t rm_groups, int32_t* cuts_out);
+/* Front-to-back compositing order of the slabs for a given zBoundary (VPR.cs:652-711 at slab granularity) and the blend plan of their
+ * partial images: chain_out[world] = ranks front to back (the slab straddling zBoundary first, then the phase-A slabs zz descending, then
+ * the phase-B slabs zz ascending); plan_rank/plan_which/plan_kind [<= world + 1] = partial images in blend order (which 0 = the slab's
+ * first image, 1 = the straddler's phase-B image; kind 0 OVER, 1 UNDER); returns the plan length in *n_plan, the straddler or -1. */
+int  vp_blend_plan(int32_t world, const int32_t* cuts, int32_t z_boundary, int32_t* chain_out, int32_t* plan_rank, int32_t* plan_which,
+                   int32_t* plan_kind, int32_t* n_plan, int32_t* straddler);
+
+/* ---- multi-GPU building blocks (one context per GPU, each owning a contiguous zz slab; what the fan-out is made of) ------------ */
 /* Fill split at the only cross-slab dependency, the per-column transmitted light (Fill.shader:224,250):
  *   vp_fill_local   : density/ao of the slab + slab transmittance map tau (computed with T_in = 1)
  *                     written to d_tau_out [(Ny*nv)][(Nx*nv)] f32 (device);
@@ -263,6 +322,17 @@ int  vp_fill_finish_gathered(vp_ctx* ctx, const void* d_tau_all, int32_t rank, i
  * the OVER image is non-empty, bit1 for UNDER. */
 int  vp_raymarch_partial_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params,
                                 void* d_over, void* d_under, int32_t* phase_mask);
+/* The same with the cross-slab saturation hand-off (the reference's one render target sees every metavoxel, VPR.cs:652-711, so a single GPU
+ * stops a ray once it is saturated; a slab alone only knows its own metavoxels):
+ *   d_t_in   n_in maps [n_in][H][W] f32 (device): transmittance 1 - alpha of slabs composited IN FRONT of this one; a ray stops once
+ *            (1 - dst.a) * prod(t_in) <= 2^-25 (no map: exactly the single-GPU rule).  NULL / 0 = nothing known.
+ *   d_t_out0 [H][W] f32: this slab's own transmittance, 1 - alpha of its first image; d_t_out1 (straddling slab): that times
+ *            1 - alpha of its phase-B image.  NULL = not wanted.
+ * Also accumulates the per-slice sample profile read by vp_read_zsamples. */
+int  vp_raymarch_partial_handoff_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, void* d_over, void* d_under,
+                                        int32_t* phase_mask, const void* d_t_in, int32_t n_in, void* d_t_out0, void* d_t_out1);
+/* Lattice samples the last vp_raymarch_partial* call executed per light-axis slice zz [Nz] (0 outside the owned slab). */
+int  vp_read_zsamples(vp_ctx* ctx, int64_t* samples_per_z);
 /* Ordered final blend of gathered partial images (VPR.cs:652-711 restricted to slab granularity):
  * d_partials[i] (device pointers, host array) are applied in the given order, kinds[i] = 0 OVER, 1 UNDER. */
 int  vp_blend_partials_device(vp_ctx* ctx, const void* const* d_partials, const int32_t* kinds, int32_t n,

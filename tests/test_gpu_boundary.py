@@ -246,18 +246,25 @@ def test_manager_first_frame_always_fills():
     np.testing.assert_array_equal(img, ref)
 
 
-def test_displacement_scale_one_takes_the_bit_exact_kernels():
+def test_displacement_scale_one_never_flips_a_voxel_across_the_smoothstep_jump():
     """Fuzz finding (seeds 404209 / 407542 / 409081 of scripts/fuzz_parity.py): with displacement scale exactly 1 the reference's smoothstep
-    jumps at net displacement 0, so reciprocal-based texture coordinates flipped a voxel now and then.  Such fills run the EXACT kernels:
-    bricks bit-identical to the oracle in default-math contexts too, white-noise byte map or float map."""
-    rng = np.random.default_rng(404209)
-    for fmt in ("r8", "f32"):
-        sc = S.make_scene("d1", dims=(2, 32, 600, 64, 48), fade=1)
-        cube = rng.integers(0, 256, size=(6, 128, 128), dtype=np.uint8)
-        sc.cubemap = cube if fmt == "r8" else np.ascontiguousarray(cube.astype(np.float32) / np.float32(255.0))
-        sc.displacement_scale = 1.0
-        o, g = both(sc)
-        cnt = o.bin_counts()
-        for zz, yy, xx in zip(*np.nonzero(cnt)):
-            assert np.array_equal(o.read_brick(xx, yy, zz).view(np.uint16), g.read_brick(xx, yy, zz).view(np.uint16)), (fmt, xx, yy, zz)
-        np.testing.assert_array_equal(o.read_lightmap(), g.read_lightmap())
+    jumps at net displacement 0, so reciprocal-based texture coordinates flipped a voxel now and then (density 0 <-> opacityFactor).  Round 2
+    sent such fills to the EXACT kernels (2x the time); now the default-math kernels -- LDS byte table for r8, global table for f32 -- recompute
+    the in-face coordinates with the oracle's IEEE arithmetic whenever a lane's coordinate is within 1e-4 of an integer (cube_address, DONE):
+    no voxel may change sides (<= 1 fp16 ulp / 2e-5 absolute like every default-math fill), on the white-noise maps that provoked the flips."""
+    for seed in (404209, 407542, 409081):
+        rng = np.random.default_rng(seed)
+        for fmt in ("r8", "f32"):
+            sc = S.make_scene("d1", dims=(2, 32, 600, 64, 48), fade=1, seed=seed)
+            cube = rng.integers(0, 256, size=(6, 128, 128), dtype=np.uint8)
+            cube[rng.random(cube.shape) < 0.25] = 0                  # many zero texels: net displacement 0 wherever a weight is exactly 0
+            sc.cubemap = cube if fmt == "r8" else np.ascontiguousarray(cube.astype(np.float32) / np.float32(255.0))
+            sc.displacement_scale = 1.0
+            o, g = both(sc)
+            cnt = o.bin_counts()
+            for zz, yy, xx in zip(*np.nonzero(cnt)):
+                fa, fb = o.read_brick(xx, yy, zz), g.read_brick(xx, yy, zz)
+                du = np.abs(fa.view(np.uint16).astype(np.int32) - fb.view(np.uint16).astype(np.int32))
+                bad = du > 1
+                assert not bad.any() or float(np.abs(fa.astype(np.float32) - fb.astype(np.float32))[bad].max()) <= 2e-5, (seed, fmt, xx, yy, zz)
+            np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=3e-4, atol=1e-9)   # (a flipped voxel would show as 4 %)

@@ -5,7 +5,7 @@ gaps (empty metavoxels are skipped, VPR.cs:511), columns with no occupied metavo
 import numpy as np
 import pytest
 
-from vpfx_amd import engine as E, scene as S
+from vpfx_amd import abi, engine as E, scene as S
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -105,13 +105,14 @@ def test_tag_range_wraps_after_many_launches_on_a_deep_grid():
             np.testing.assert_array_equal(g.read_brick(0, 0, zz0), b0)
 
 
-def test_watchdog_reports_a_hand_off_that_never_arrives():
-    """vp_config.reserved[2] = 1 (test hook): units await tags nobody writes and give up after a few polls.  The fill then completes --
-    no hung GPU -- and the next synchronising call returns an error; the context stays usable."""
+def test_watchdog_reports_a_hand_off_that_never_arrives(monkeypatch):
+    """Test hook VPFX_TEST_CHAIN_TIMEOUT=1 (environment, read by vp_create; not reachable through the ABI structs): units await tags nobody
+    writes and give up after a few polls.  The fill then completes -- no hung GPU --, the next synchronising call returns an error, the fill
+    counts as not done (a ray-march must not composite its bricks), and the context stays usable."""
     sc = S.make_scene("C1", cubemap="r8")
-    cfg = sc.config()
-    cfg.reserved[2] = 1
-    g = E.Engine(cfg)
+    monkeypatch.setenv("VPFX_TEST_CHAIN_TIMEOUT", "1")
+    g = E.Engine(sc.config())
+    monkeypatch.delenv("VPFX_TEST_CHAIN_TIMEOUT")
     g.set_frame(sc.light_to_world, sc.grid_center)
     g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     g.fill(sc.fill_params())
@@ -119,3 +120,19 @@ def test_watchdog_reports_a_hand_off_that_never_arrives():
         g.sync()
     g.sync()                                                       # the flag is consumed: the context keeps working
     assert g.stats()["occupied_mv"] > 0
+    with pytest.raises(E.VpfxError) as ei:                         # ... but the timed-out fill is invalid: no ray-march on it
+        g.raymarch(sc.camera(), sc.raymarch_params())
+    assert ei.value.code == abi.VP_ERR_STATE
+    # the device-async entry point never syncs: it must see the flag too
+    import torch
+    g.fill(sc.fill_params())
+    torch.cuda.synchronize()
+    out = torch.empty((sc.height, sc.width, 4), device="cuda")
+    with pytest.raises(Exception, match="hand-off"):
+        g.raymarch_device(sc.camera(), sc.raymarch_params(), out.data_ptr())
+    # reserved switches outside the documented values are refused (an uninitialised struct must not silently change behaviour)
+    cfg = sc.config()
+    cfg.reserved[2] = 1
+    with pytest.raises(E.VpfxError) as ei:
+        E.Engine(cfg)
+    assert ei.value.code == abi.VP_ERR_BAD_ARG

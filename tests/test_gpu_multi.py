@@ -1,0 +1,195 @@
+"""The multi-GPU fan-out BEHIND the C ABI (vp_config.num_devices / devices[], csrc/multi.cpp) on ONE GPU.
+
+VP_MULTI_PEER_COPY is the library's test hook: the device list may repeat ({0,0,..}: N slabs on one GPU) and every exchange is a
+device-to-device copy between the local slab contexts instead of an RCCL call.  Everything else is the production path: the same
+vp_set_frame / vp_bin / vp_fill / vp_raymarch calls a single-GPU host makes, one worker thread + stream per rank, the library's own slab
+cut, the tau all-gather, the saturation hand-off between slab groups, the image exchange (both forms) and the ordered blend.
+The fan-out must reproduce the single context (<= 2e-5) and the oracle (<= 1e-3); with a fully serial hand-off chain the ranks together
+must execute the single GPU's sample count (the reference's one render target sees every metavoxel: VPR.cs:652-711).
+VP_MULTI_FORCE runs the same path with ONE rank on a real RCCL communicator (ncclCommInitAll + all-gather on one GPU)."""
+import numpy as np
+import pytest
+
+from vpfx_amd import abi, engine as E, scene as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(eng, sc, fill=True):
+    eng.set_frame(sc.light_to_world, sc.grid_center)
+    eng.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    if fill:
+        eng.fill(sc.fill_params())
+    return eng.raymarch(sc.camera(), sc.raymarch_params())
+
+
+def _single(sc, **kw):
+    e = E.Engine(sc.config(), **kw)
+    img = _frame(e, sc)
+    return e, img
+
+
+def _fanout(sc, world, flags=0, groups=0, **kw):
+    return E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY | flags, rm_groups=groups), **kw)
+
+
+@pytest.mark.parametrize("world,flags", [(2, 0), (4, 0), (3, abi.VP_MULTI_EXCHANGE_ALL_GATHER), (4, abi.VP_MULTI_UNIFORM_SLABS)])
+def test_fanout_matches_single_context_and_oracle(world, flags):
+    sc = S.make_scene("C1", cubemap="r8")
+    single, ref = _single(sc)
+    m = _fanout(sc, world, flags)
+    img = _frame(m, sc)
+    assert np.abs(img - ref).max() <= 2e-5
+    o = O.Oracle(sc.config())
+    assert np.abs(img - _frame(o, sc)).max() <= 1e-3
+    info = m.multi_info()
+    assert info["world_size"] == world and info["num_local"] == world and info["rccl_ranks"] == 0
+    cuts = info["slab_cuts"]
+    assert cuts[0] == 0 and cuts[-1] == sc.N[2] and all(b > a for a, b in zip(cuts, cuts[1:]))
+    assert info["exchange"] == ("all_gather" if flags & abi.VP_MULTI_EXCHANGE_ALL_GATHER else "tiles")
+    # the same probes as on a single context: bins, bricks, light map, stats
+    assert np.array_equal(m.bin_counts(), single.bin_counts())
+    np.testing.assert_allclose(m.read_lightmap(), single.read_lightmap(), rtol=2e-5, atol=1e-9)
+    cnt = single.bin_counts()
+    zz, yy, xx = np.nonzero(cnt)
+    for i in range(0, len(zz), max(1, len(zz) // 16)):
+        a = single.read_brick(xx[i], yy[i], zz[i]).view(np.uint16).astype(np.int32)
+        b = m.read_brick(xx[i], yy[i], zz[i]).view(np.uint16).astype(np.int32)
+        assert np.abs(a - b).max() <= 1                      # T_in = product of the nearer slabs' maps: reassociated, <= 1 fp16 ulp
+        assert np.array_equal(m.bin_list(xx[i], yy[i], zz[i]), single.bin_list(xx[i], yy[i], zz[i]))
+    st, s1 = m.stats(), single.stats()
+    for key in ("particles", "occupied_mv", "pairs", "voxels_filled"):
+        assert st[key] == s1[key], key
+    # a second frame on the same context: other camera (straddling zBoundary), rebalanced slabs
+    sc.set_camera((2.0, 1.0, -1.5))
+    cam, rp = sc.camera(), sc.raymarch_params()
+    ref2 = single.raymarch(cam, rp)
+    m.rebalance()
+    m.bin_resident()
+    m.fill(sc.fill_params())
+    img2 = m.raymarch(cam, rp)
+    assert np.abs(img2 - ref2).max() <= 2e-5
+    m.close()
+    single.close()
+
+
+def test_serial_handoff_chain_executes_the_single_gpu_sample_count():
+    """rm_groups = world: every slab knows the opacity of all slabs in front of it, like the reference's single render target."""
+    sc = S.make_scene("C2", cubemap="r8")
+    sc.opacity_factor = 0.2                                   # a dense medium: most rays saturate inside the grid
+    single, ref = _single(sc)
+    s1 = single.stats()["samples"]
+    no_eo = E.Engine(sc.config(), early_out=False)
+    _frame(no_eo, sc)
+    lattice = no_eo.stats()["samples"]
+    no_eo.close()
+    assert lattice > 1.3 * s1                                 # the early-out matters in this scene
+    counts = {}
+    for groups in (1, 2, 4):
+        m = _fanout(sc, 4, groups=groups)
+        img = _frame(m, sc)
+        assert np.abs(img - ref).max() <= 2e-5, groups
+        counts[groups] = m.stats()["samples"]
+        info = m.multi_info()
+        assert info["rm_groups"] == groups and sorted(info["chain"]) == [0, 1, 2, 3]
+        assert sum(info["samples"]) == counts[groups]
+        m.close()
+    assert counts[4] <= 1.02 * s1, (counts, s1)               # the serial chain: the single GPU's samples (+- rounding of the product)
+    assert counts[4] >= 0.98 * s1
+    assert counts[1] >= counts[2] >= counts[4]                # fewer groups, more hidden samples marched
+    assert counts[1] <= lattice
+    single.close()
+
+
+@pytest.mark.parametrize("cam_pos", [(0.5, 0.3, 1.0), (1.0, 12.0, 2.0), (0.0, 0.0, 40.0)])
+def test_handoff_with_a_camera_inside_and_behind_the_grid(cam_pos):
+    """zBoundary inside the grid: one slab straddles it and is composited first; phase-A slabs behind it are hidden by its phase-A image only."""
+    sc = S.make_scene("C1", cubemap="r8")
+    sc.set_camera(cam_pos)
+    single, ref = _single(sc)
+    s1 = single.stats()["samples"]
+    for groups in (1, 4):
+        m = _fanout(sc, 4, groups=groups)
+        img = _frame(m, sc)
+        assert np.abs(img - ref).max() <= 2e-5, (cam_pos, groups)
+        if groups == 4:
+            assert m.stats()["samples"] <= 1.05 * s1 + 1000   # (the straddling slab's phase-B part only knows its own phase-A part)
+        m.close()
+    single.close()
+
+
+def test_one_rank_on_a_real_rccl_communicator():
+    """VP_MULTI_FORCE: the fan-out path with one rank -- librccl is dlopen()ed, ncclCommInitAll + ncclAllGather run on this GPU."""
+    sc = S.make_scene("T0")
+    single, ref = _single(sc)
+    m = E.Engine(sc.config(devices=[0], multi_flags=abi.VP_MULTI_FORCE))
+    img = _frame(m, sc)
+    info = m.multi_info()
+    assert info["world_size"] == 1 and info["rccl_ranks"] == 1
+    assert np.abs(img - ref).max() <= 2e-5
+    uid = E.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    # the multi-process form of the same thing: a 1-rank job created from a unique id (ncclCommInitRank)
+    m2 = E.Engine(sc.config(devices=[0], world_size=1, first_rank=0, multi_flags=abi.VP_MULTI_FORCE, rccl_unique_id=uid))
+    assert np.abs(_frame(m2, sc) - ref).max() <= 2e-5 and m2.multi_info()["rccl_ranks"] == 1
+    for x in (m, m2, single):
+        x.close()
+
+
+def test_fanout_argument_errors():
+    sc = S.make_scene("T0")
+    for bad in (dict(devices=[0, 0]),                                              # a GPU twice without the test hook
+                dict(devices=[0] * 2, multi_flags=abi.VP_MULTI_PEER_COPY, world_size=4, first_rank=0),   # hook needs every rank local
+                dict(devices=[0] * 8, multi_flags=abi.VP_MULTI_PEER_COPY),         # more slabs than light-axis slices (T0 has 4)
+                dict(devices=[99, 98], multi_flags=abi.VP_MULTI_PEER_COPY)):
+        with pytest.raises(E.VpfxError) as ei:
+            E.Engine(sc.config(**bad))
+        assert ei.value.code == abi.VP_ERR_BAD_ARG, bad
+    m = _fanout(sc, 2)
+    _frame(m, sc)
+    with pytest.raises(E.VpfxError) as ei:                    # the per-metavoxel entry points are single-context calls
+        m.fill_metavoxel(0, 0, 0)
+    assert ei.value.code == abi.VP_ERR_UNSUPPORTED
+    m.close()
+
+
+def test_partial_raymarch_handoff_entry_point_on_separate_contexts():
+    """vp_raymarch_partial_handoff_device, the building block hosts with their own transport (parallel.py over torch.distributed) use."""
+    import torch
+    sc = S.make_scene("C1", cubemap="r8")
+    single, ref = _single(sc)
+    s1 = single.stats()["samples"]
+    dev = torch.device("cuda", 0)
+    bounds = [(0, 3), (3, 8)]
+    engs = []
+    for b in bounds:
+        e = E.Engine(sc.config(device=0, slab=b))
+        e.set_frame(sc.light_to_world, sc.grid_center)
+        e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+        e.bin_resident()
+        engs.append(e)
+    lm = (sc.N[1] * sc.nv, sc.N[0] * sc.nv)
+    tau = torch.empty((2,) + lm, device=dev)
+    for r, e in enumerate(engs):
+        e.fill_local(sc.fill_params(), tau[r].data_ptr())
+    for r, e in enumerate(engs):
+        e.fill_finish_gathered(tau.data_ptr(), r, 2)
+    cam, rp = sc.camera(), sc.raymarch_params()
+    img = [[torch.empty((sc.height, sc.width, 4), device=dev) for _ in range(2)] for _ in range(2)]
+    t_out = torch.empty((2, 2, sc.height, sc.width), device=dev)
+    engs[0].raymarch_partial_handoff_device(cam, rp, img[0][0].data_ptr(), img[0][1].data_ptr(), 0, 0, t_out[0, 0].data_ptr(), t_out[0, 1].data_ptr())
+    engs[1].raymarch_partial_handoff_device(cam, rp, img[1][0].data_ptr(), img[1][1].data_ptr(), t_out[0, 1].data_ptr(), 1, t_out[1, 0].data_ptr(),
+                                            t_out[1, 1].data_ptr())
+    out = torch.empty((sc.height, sc.width, 4), device=dev)
+    engs[0].blend_partials_device([img[0][1].data_ptr(), img[1][1].data_ptr()], [1, 1], out.data_ptr())     # zBoundary -1: both UNDER
+    engs[0].sync()
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5
+    total = engs[0].stats()["samples"] + engs[1].stats()["samples"]
+    assert 0.98 * s1 <= total <= 1.02 * s1
+    zs = [e.zsamples() for e in engs]
+    assert zs[0][3:].sum() == 0 and zs[1][:3].sum() == 0 and zs[0].sum() == engs[0].stats()["samples"] and zs[1].sum() == engs[1].stats()["samples"]
+    t = t_out.cpu().numpy()
+    assert np.all((t >= 0) & (t <= 1)) and np.allclose(t[0, 1], 1.0 - img[0][1][..., 3].cpu().numpy(), atol=1e-6)
+    for e in engs + [single]:
+        e.close()

@@ -12,6 +12,14 @@ VP_ERR_OOM = -3
 VP_ERR_STATE = -4
 VP_ERR_NO_DEVICE = -5
 VP_ERR_UNSUPPORTED = -6
+VP_ERR_RCCL = -7
+
+VP_MAX_LOCAL_DEVICES = 8
+VP_MAX_RANKS = 16
+VP_MULTI_PEER_COPY = 1             # test hook: no RCCL, device-to-device copies between the local slab contexts (devices may repeat)
+VP_MULTI_EXCHANGE_ALL_GATHER = 2
+VP_MULTI_UNIFORM_SLABS = 4
+VP_MULTI_FORCE = 8
 
 VP_RM_QUANTIZE_UNORM8 = 1
 VP_RM_SHOW_NUM_SAMPLES = 2
@@ -22,11 +30,11 @@ VP_BRICKS_RGBA16F, VP_BRICKS_GREY_ZPAIR = 0, 1
 VP_CUBEMAP_F32 = 0
 VP_CUBEMAP_R8 = 1
 
-VPFX_ABI_VERSION = 2
+VPFX_ABI_VERSION = 3
 
 STATUS_NAMES = {
     0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
-    -4: "VP_ERR_STATE", -5: "VP_ERR_NO_DEVICE", -6: "VP_ERR_UNSUPPORTED",
+    -4: "VP_ERR_STATE", -5: "VP_ERR_NO_DEVICE", -6: "VP_ERR_UNSUPPORTED", -7: "VP_ERR_RCCL",
 }
 
 c_float_p = C.POINTER(C.c_float)
@@ -65,6 +73,31 @@ class vp_config(C.Structure):
         ("exact_math", C.c_int32),
         ("no_early_out", C.c_int32),
         ("reserved", C.c_int32 * 3),
+        # ABI 3: multi-GPU fan-out inside the library
+        ("num_devices", C.c_int32),
+        ("devices", C.c_int32 * 8),
+        ("world_size", C.c_int32),
+        ("first_rank", C.c_int32),
+        ("multi_flags", C.c_int32),
+        ("rm_groups", C.c_int32),
+        ("rccl_unique_id", C.c_uint8 * 128),
+    ]
+
+
+class vp_multi_info(C.Structure):
+    _fields_ = [
+        ("world_size", C.c_int32),
+        ("num_local", C.c_int32),
+        ("first_rank", C.c_int32),
+        ("rccl_ranks", C.c_int32),
+        ("exchange", C.c_int32),
+        ("rm_groups", C.c_int32),
+        ("slab_cuts", C.c_int32 * (VP_MAX_RANKS + 1)),
+        ("chain", C.c_int32 * VP_MAX_RANKS),
+        ("group_of", C.c_int32 * VP_MAX_RANKS),
+        ("samples", C.c_int64 * VP_MAX_RANKS),
+        ("stage_ms", (C.c_float * 4) * VP_MAX_RANKS),
+        ("exchange_ms", C.c_float * 4),
     ]
 
 
@@ -149,4 +182,6 @@ EXPORTED_SYMBOLS = [
     "vp_z_boundary", "vp_z_histogram", "vp_set_occluders", "vp_render_light_depth", "vp_render_scene_depth",
     "vp_get_mv_positions", "vp_read_binlist", "vp_read_bincounts", "vp_read_brick",
     "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",
+    "vp_raymarch_partial_handoff_device", "vp_read_zsamples",
+    "vp_get_multi_info", "vp_rebalance", "vp_rccl_unique_id", "vp_plan_slabs", "vp_blend_plan",
 ]

@@ -38,16 +38,23 @@ int ensure_device(vp_ctx* c)
     return VP_OK;
 }
 
-// Stream sync of the host-facing entry points + the chained fill's watchdog flag (a unit that waited ~seconds for its column's light
-// sets it and carries on with whatever it read: an error the caller sees instead of a hung GPU).
-int stream_sync(vp_ctx* c)
+// The chained fill's watchdog flag (a unit that waited ~seconds for its column's light sets it and carries on with whatever it read: an
+// error the caller sees instead of a hung GPU).  A set flag invalidates the fill: the bricks must not be composited.
+int check_chain_error(vp_ctx* c)
 {
-    VP_HIP(hipStreamSynchronize(c->stream));
     if (c->h_chain_err && *(volatile int*)c->h_chain_err) {
         *(volatile int*)c->h_chain_err = 0;
+        c->filled = c->local_done = false;
         return vp_fail(c, VP_ERR_HIP, "fill: a light hand-off between metavoxel units timed out (results of the last fill are invalid)");
     }
     return VP_OK;
+}
+
+// Stream sync of the host-facing entry points + the watchdog flag.
+int stream_sync(vp_ctx* c)
+{
+    VP_HIP(hipStreamSynchronize(c->stream));
+    return check_chain_error(c);
 }
 
 size_t lightmap_elems(const vp_ctx* c) { return (size_t)c->g.Nx * c->g.nv * c->g.Ny * c->g.nv; }
@@ -99,7 +106,6 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
             c->cubeS = 0;                                      // no table resident until the new one is allocated AND built
             VP_HIP(hipMalloc((void**)&c->d_cubequads, (size_t)6 * (S + 1) * (S + 2) * sizeof(float2) + 16));
         }
-        const int keepS = c->cubeS;
         c->cubeS = 0;                                          // the resident table is being overwritten: invalid until it is rebuilt
         void* d_cube = nullptr;
         const size_t bytes = (size_t)6 * S * S * (p->cubemap_format == VP_CUBEMAP_R8 ? 1 : sizeof(float));
@@ -124,7 +130,6 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamSynchronize(c->stream);       // the caller's cubemap pointer is not retained
         (void)hipFree(d_cube);
-        (void)keepS;
         if (e != hipSuccess || e2 != hipSuccess) return vp_fail(c, VP_ERR_HIP, "cubemap upload failed");
         if (rc) return rc;
         if (bad) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: displacement cubemap has texels outside [0, 1] (or NaN)");
@@ -159,6 +164,7 @@ int check_fill_ready(vp_ctx* c, const char* who)
 int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k)
 {
     if (!cam || !rp) return vp_fail(c, VP_ERR_BAD_ARG, "null camera / params");
+    { int rce = check_chain_error(c); if (rce) return rce; }   // a fill that already reported a timed-out hand-off must not be composited
     if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_raymarch before vp_fill");
     if (rp->steps_per_mv < 1 || rp->soft_distance < 1) return vp_fail(c, VP_ERR_BAD_ARG, "steps_per_mv and soft_distance must be >= 1");
     if ((rp->flags & VP_RM_SHOW_DRAW_ORDER) && (c->g.z0 != 0 || c->g.z1 != c->g.Nz))
@@ -181,6 +187,23 @@ int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp
 
 }  // namespace
 
+// the single-device building blocks the fan-out (multi.cpp) runs on its slab contexts
+int api_stream_sync(vp_ctx* c) { return stream_sync(c); }
+int api_stage_fill_inputs(vp_ctx* c, const vp_fill_params* p) { return stage_fill_inputs(c, p); }
+int api_ensure_bricks(vp_ctx* c, bool need_scratch) { return ensure_bricks(c, need_scratch); }
+int api_stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k) { return stage_raymarch(c, cam, rp, k); }
+int api_set_slab(vp_ctx* c, int z0, int z1)
+{
+    if (z0 < 0 || z1 > c->g.Nz || z0 >= z1) return vp_fail(c, VP_ERR_BAD_ARG, "bad slab [%d,%d)", z0, z1);
+    c->cfg.slab_z0 = z0; c->cfg.slab_z1 = z1;
+    c->g.z0 = z0; c->g.z1 = z1;
+    c->binned = c->filled = c->local_done = c->fill_begun = false;
+    return VP_OK;
+}
+
+#define VP_NO_FANOUT(c, what)                                                                                                   \
+    do { if ((c)->multi) return vp_fail((c), VP_ERR_UNSUPPORTED, what ": not available on a fan-out (multi-GPU) context"); } while (0)
+
 // --------------------------------------------------------------------------------------------------
 VP_EXPORT int vp_abi_version(void) { return VPFX_ABI_VERSION; }
 
@@ -188,8 +211,22 @@ VP_EXPORT const char* vp_last_error(const vp_ctx* c) { return c ? c->err.c_str()
 
 VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
 {
-    vp_ctx* c = nullptr;
     if (!cfg || !out) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: null argument");
+    *out = nullptr;
+    if (cfg->num_devices < 0 || cfg->num_devices > VP_MAX_LOCAL_DEVICES || cfg->world_size < 0 || cfg->world_size > VP_MAX_RANKS)
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: num_devices %d / world_size %d out of range", cfg->num_devices, cfg->world_size);
+    if (cfg->num_devices > 1 || cfg->world_size > 1 || (cfg->multi_flags & VP_MULTI_FORCE)) return multi_create(cfg, out);
+    if (cfg->num_devices == 1) {                              // a one-entry device list is just that device
+        vp_config one = *cfg;
+        one.device = cfg->devices[0];
+        return vp_create_single(&one, out);
+    }
+    return vp_create_single(cfg, out);
+}
+
+int vp_create_single(const vp_config* cfg, vp_ctx** out)
+{
+    vp_ctx* c = nullptr;
     *out = nullptr;
     const int nv = cfg->num_voxels;
     if (cfg->num_mv[0] < 1 || cfg->num_mv[1] < 1 || cfg->num_mv[2] < 1 || !(cfg->mv_scale > 0.f) || cfg->num_border < 0 ||
@@ -197,6 +234,9 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
         return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: bad grid/screen configuration");
     if (nv != 16 && nv != 32 && nv != 64)
         return vp_fail(nullptr, VP_ERR_UNSUPPORTED, "vp_create: num_voxels %d not built (16, 32, 64)", nv);
+    if ((cfg->reserved[0] != 0 && cfg->reserved[0] != 1) || (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) || cfg->reserved[2] != 0)
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: vp_config.reserved = {%d, %d, %d} (0 or the documented switches; an uninitialised struct?)",
+                       cfg->reserved[0], cfg->reserved[1], cfg->reserved[2]);
     if ((size_t)cfg->num_mv[0] * cfg->num_mv[1] * cfg->num_mv[2] > ((size_t)1 << 28))
         return vp_fail(nullptr, VP_ERR_UNSUPPORTED, "vp_create: grid too large");
     int z0 = cfg->slab_z0, z1 = cfg->slab_z1;
@@ -216,13 +256,14 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
     if (!c) return vp_fail(nullptr, VP_ERR_OOM, "vp_create: host allocation failed");
     c->cfg = *cfg;
     c->device = dev;
+    { const char* hook = getenv("VPFX_TEST_CHAIN_TIMEOUT"); c->test_chain_timeout = hook && hook[0] == '1'; }
     c->n3 = (size_t)cfg->num_mv[0] * cfg->num_mv[1] * cfg->num_mv[2];
     // identity frame until vp_set_frame
     memset(c->L, 0, sizeof c->L); c->L[0] = c->L[5] = c->L[10] = c->L[15] = 1.f;
     c->h_mvPos = (float*)malloc(c->n3 * 3 * sizeof(float));
     c->h_rank = (int*)malloc((size_t)cfg->num_mv[0] * cfg->num_mv[1] * sizeof(int));
     int rc = VP_OK;
-    auto fail = [&](int code) { g_vp_create_error = c->err; vp_destroy(c); return code; };
+    auto fail = [&](int code) { g_vp_create_error = c->err; vp_destroy_single(c); return code; };
     if (!c->h_mvPos || !c->h_rank) { c->err = "vp_create: host allocation failed"; return fail(VP_ERR_OOM); }
     hl_build_grid(c);
     if ((rc = ensure_device(c))) return fail(rc);
@@ -236,6 +277,7 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, (int4**)&c->d_scan_totals, (c->n3 + 1023) / 1024 + 1)) ||
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
+        (rc = dev_alloc(c, &c->d_zsamples, (size_t)cfg->num_mv[2])) ||
         (rc = dev_alloc(c, &c->d_cam_rows, 12)) || (rc = dev_alloc(c, &c->d_tile_order, 2 * ((size_t)rm_num_super_tiles(cfg->width, cfg->height) + 8))))
         return fail(rc);
     if (hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -252,11 +294,18 @@ VP_EXPORT int vp_create(const vp_config* cfg, vp_ctx** out)
 VP_EXPORT void vp_destroy(vp_ctx* c)
 {
     if (!c) return;
+    if (c->multi) { multi_destroy(c); return; }
+    vp_destroy_single(c);
+}
+
+void vp_destroy_single(vp_ctx* c)
+{
+    if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
-                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples};
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
@@ -268,6 +317,7 @@ VP_EXPORT int vp_pin_host_buffer(vp_ctx* c, void* ptr, uint64_t bytes)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!ptr || !bytes) return vp_fail(c, VP_ERR_BAD_ARG, "vp_pin_host_buffer: null buffer");
+    if (c->multi) { VP_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable)); return VP_OK; }     // visible to every device
     int rc = ensure_device(c); if (rc) return rc;
     VP_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
     return VP_OK;
@@ -277,6 +327,7 @@ VP_EXPORT int vp_unpin_host_buffer(vp_ctx* c, void* ptr)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!ptr) return vp_fail(c, VP_ERR_BAD_ARG, "vp_unpin_host_buffer: null buffer");
+    if (c->multi) { int rcm = multi_sync(c); if (rcm) return rcm; VP_HIP(hipHostUnregister(ptr)); return VP_OK; }
     int rc = ensure_device(c); if (rc) return rc;
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     VP_HIP(hipHostUnregister(ptr));
@@ -286,6 +337,7 @@ VP_EXPORT int vp_unpin_host_buffer(vp_ctx* c, void* ptr)
 VP_EXPORT int vp_set_stream(vp_ctx* c, void* hip_stream)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    VP_NO_FANOUT(c, "vp_set_stream (a fan-out context owns one stream per device)");
     c->stream = (hipStream_t)hip_stream;
     return VP_OK;
 }
@@ -293,6 +345,7 @@ VP_EXPORT int vp_set_stream(vp_ctx* c, void* hip_stream)
 VP_EXPORT int vp_sync(vp_ctx* c)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    if (c->multi) return multi_sync(c);
     int rc = ensure_device(c); if (rc) return rc;
     { int rcs = stream_sync(c); if (rcs) return rcs; }
     return VP_OK;
@@ -302,6 +355,7 @@ VP_EXPORT int vp_set_frame(vp_ctx* c, const float light_to_world[16], const floa
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!light_to_world || !grid_center) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_frame: null argument");
+    if (c->multi) return multi_set_frame(c, light_to_world, grid_center);
     int rc = ensure_device(c); if (rc) return rc;
     memcpy(c->L, light_to_world, sizeof c->L);
     memcpy(c->gc, grid_center, sizeof c->gc);
@@ -317,6 +371,12 @@ VP_EXPORT int vp_upload_particles(vp_ctx* c, const void* particles, int32_t coun
                                   const float psys_local_to_world[16])
 {
     if (!c) return VP_ERR_BAD_ARG;
+    if (c->multi) return multi_upload_particles(c, particles, count, lay, psys_local_to_world);
+    return api_upload_particles(c, particles, count, lay, psys_local_to_world, true);
+}
+
+int api_upload_particles(vp_ctx* c, const void* particles, int32_t count, const vp_particle_layout* lay, const float* psys_local_to_world, bool sync)
+{
     if ((!particles && count > 0) || count < 0 || !lay || !psys_local_to_world)
         return vp_fail(c, VP_ERR_BAD_ARG, "vp_upload_particles: null/negative argument");
     const int32_t offs[5] = {lay->off_position + 8, lay->off_size, lay->off_rotation, lay->off_lifetime, lay->off_start_lifetime};
@@ -347,7 +407,7 @@ VP_EXPORT int vp_upload_particles(vp_ctx* c, const void* particles, int32_t coun
     if (count > 0) {
         VP_HIP(hipMemcpyAsync(c->d_raw, particles, bytes, hipMemcpyHostToDevice, c->stream));
         rc = launch_extract(c); if (rc) return rc;
-        { int rcs = stream_sync(c); if (rcs) return rcs; }               // caller's array is not retained past return
+        if (sync) { int rcs = stream_sync(c); if (rcs) return rcs; }     // caller's array is not retained past return (the fan-out syncs all devices itself)
     }
     c->have_particles = true;
     c->binned = c->filled = c->local_done = false;
@@ -357,6 +417,7 @@ VP_EXPORT int vp_upload_particles(vp_ctx* c, const void* particles, int32_t coun
 VP_EXPORT int vp_bin_resident(vp_ctx* c)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    if (c->multi) return multi_bin_resident(c);
     if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_bin before vp_set_frame");
     if (!c->have_particles) return vp_fail(c, VP_ERR_STATE, "vp_bin_resident before vp_upload_particles");
     int rc = ensure_device(c); if (rc) return rc;
@@ -370,6 +431,7 @@ VP_EXPORT int vp_z_histogram(vp_ctx* c, int64_t* pairs_per_z)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!pairs_per_z) return vp_fail(c, VP_ERR_BAD_ARG, "vp_z_histogram: null output");
+    VP_NO_FANOUT(c, "vp_z_histogram");
     if (!c->have_frame || !c->have_particles) return vp_fail(c, VP_ERR_STATE, "vp_z_histogram needs vp_set_frame and vp_upload_particles");
     int rc = ensure_device(c); if (rc) return rc;
     // d_cursor is free between bins (k_scan rewrites it); Nz <= N^3 ints
@@ -397,6 +459,7 @@ VP_EXPORT int vp_fill(vp_ctx* c, const vp_fill_params* p)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!p) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill: null params");
+    if (c->multi) return multi_fill(c, p);
     int rc = check_fill_ready(c, "vp_fill"); if (rc) return rc;
     if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, false))) return rc;
     rc = launch_fill(c, 0, nullptr, c->d_lightmap); if (rc) return rc;
@@ -409,11 +472,16 @@ VP_EXPORT int vp_fill_begin(vp_ctx* c, const vp_fill_params* p)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!p) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill_begin: null params");
+    VP_NO_FANOUT(c, "vp_fill_begin");
     int rc = check_fill_ready(c, "vp_fill_begin"); if (rc) return rc;
     const size_t cap0 = c->brick_cap;
     if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, false))) return rc;
-    // a freshly (re)allocated pool holds no textures yet: RenderTexture contents start out cleared
-    if (c->brick_cap != cap0) VP_HIP(hipMemsetAsync(c->d_bricks, 0, c->brick_cap * nv3(c) * sizeof(uint2), c->stream));
+    // a freshly (re)allocated pool holds no textures yet: RenderTexture contents start out cleared.  So does a pool whose storage format
+    // changes with this fill (grey z-pair entries <-> RGBA16F, decided by the ambient colour): per-metavoxel fills only rewrite the bricks
+    // they are called for, and the ray-march reads every brick in ONE format -- a brick left over in the other one would render as garbage.
+    const bool grey = c->fc.grey != 0;
+    if (c->brick_cap != cap0 || grey != c->bricks_grey) VP_HIP(hipMemsetAsync(c->d_bricks, 0, c->brick_cap * nv3(c) * sizeof(uint2), c->stream));
+    c->bricks_grey = grey;
     // GL.Clear(false, true, Color.red) on lightPropogationTex: 1.0 in the R channel                       VPR.cs:498-499
     rc = launch_fill_value(c, c->d_lightmap, lightmap_elems(c), 1.0f); if (rc) return rc;
     c->fill_begun = true;
@@ -424,6 +492,7 @@ VP_EXPORT int vp_fill_begin(vp_ctx* c, const vp_fill_params* p)
 VP_EXPORT int vp_fill_metavoxel(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    VP_NO_FANOUT(c, "vp_fill_metavoxel");
     if (!c->fill_begun || !c->binned) return vp_fail(c, VP_ERR_STATE, "vp_fill_metavoxel before vp_fill_begin");
     const GridConsts& g = c->g;
     if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
@@ -437,6 +506,7 @@ VP_EXPORT int vp_fill_metavoxel(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz)
 VP_EXPORT int vp_clear_particles_rt(vp_ctx* c)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    VP_NO_FANOUT(c, "vp_clear_particles_rt");
     int rc = ensure_device(c); if (rc) return rc;
     VP_HIP(hipMemsetAsync(c->d_image, 0, image_elems(c) * sizeof(float), c->stream));                     // VPR.cs:171-172
     VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
@@ -448,6 +518,7 @@ VP_EXPORT int vp_render_metavoxel(vp_ctx* c, const vp_camera* cam, const vp_raym
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!cam || !rp) return vp_fail(c, VP_ERR_BAD_ARG, "vp_render_metavoxel: null camera / params");
+    VP_NO_FANOUT(c, "vp_render_metavoxel");
     if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_render_metavoxel before vp_fill");
     if (rp->steps_per_mv < 1 || rp->soft_distance < 1) return vp_fail(c, VP_ERR_BAD_ARG, "steps_per_mv and soft_distance must be >= 1");
     const GridConsts& g = c->g;
@@ -482,6 +553,7 @@ VP_EXPORT int vp_read_particles_rt(vp_ctx* c, float* rgba_out)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_read_particles_rt: null output");
+    VP_NO_FANOUT(c, "vp_read_particles_rt");
     int rc = ensure_device(c); if (rc) return rc;
     VP_HIP(hipMemcpyAsync(rgba_out, c->d_image, image_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     { int rcs = stream_sync(c); if (rcs) return rcs; }
@@ -492,6 +564,7 @@ VP_EXPORT int vp_fill_local(vp_ctx* c, const vp_fill_params* p, void* d_tau_out)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!p || !d_tau_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill_local: null argument");
+    VP_NO_FANOUT(c, "vp_fill_local");
     int rc = check_fill_ready(c, "vp_fill_local"); if (rc) return rc;
     if ((rc = ensure_device(c)) || (rc = stage_fill_inputs(c, p)) || (rc = ensure_bricks(c, true))) return rc;
     rc = launch_fill(c, 1, nullptr, (float*)d_tau_out); if (rc) return rc;
@@ -503,6 +576,7 @@ VP_EXPORT int vp_fill_local(vp_ctx* c, const vp_fill_params* p, void* d_tau_out)
 VP_EXPORT int vp_fill_finish(vp_ctx* c, const void* d_light_in)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    VP_NO_FANOUT(c, "vp_fill_finish");
     if (!c->local_done) return vp_fail(c, VP_ERR_STATE, "vp_fill_finish before vp_fill_local");
     int rc = ensure_device(c); if (rc) return rc;
     rc = launch_fill(c, 2, (const float*)d_light_in, c->d_lightmap); if (rc) return rc;
@@ -514,6 +588,7 @@ VP_EXPORT int vp_fill_finish_gathered(vp_ctx* c, const void* d_tau_all, int32_t 
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_tau_all || world < 1 || rank < 0 || rank >= world) return vp_fail(c, VP_ERR_BAD_ARG, "vp_fill_finish_gathered: bad argument");
+    VP_NO_FANOUT(c, "vp_fill_finish_gathered");
     if (!c->local_done) return vp_fail(c, VP_ERR_STATE, "vp_fill_finish_gathered before vp_fill_local");
     int rc = ensure_device(c); if (rc) return rc;
     c->finish_tau_all = rank > 0 ? (const float*)d_tau_all : nullptr;      // rank 0: nothing nearer the light, T_in = 1
@@ -529,6 +604,7 @@ VP_EXPORT int vp_raymarch_device(vp_ctx* c, const vp_camera* cam, const vp_rayma
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch_device: null output");
+    if (c->multi) return multi_raymarch(c, cam, rp, nullptr, d_rgba_out);
     int rc = ensure_device(c); if (rc) return rc;
     RmConsts k;
     rc = stage_raymarch(c, cam, rp, &k); if (rc) return rc;
@@ -542,6 +618,7 @@ VP_EXPORT int vp_raymarch_device(vp_ctx* c, const vp_camera* cam, const vp_rayma
 VP_EXPORT int vp_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, float* rgba_out)
 {
     if (!c) return VP_ERR_BAD_ARG;
+    if (c->multi) return multi_raymarch(c, cam, rp, rgba_out, nullptr);   // (rgba_out may be NULL on processes that do not hold rank 0)
     if (!rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch: null output");
     int rc = vp_raymarch_device(c, cam, rp, c->d_image); if (rc) return rc;
     VP_HIP(hipMemcpyAsync(rgba_out, c->d_image, image_elems(c) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -552,8 +629,16 @@ VP_EXPORT int vp_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_par
 VP_EXPORT int vp_raymarch_partial_device(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, void* d_over, void* d_under,
                                          int32_t* phase_mask)
 {
+    return vp_raymarch_partial_handoff_device(c, cam, rp, d_over, d_under, phase_mask, nullptr, 0, nullptr, nullptr);
+}
+
+VP_EXPORT int vp_raymarch_partial_handoff_device(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, void* d_over, void* d_under,
+                                                 int32_t* phase_mask, const void* d_t_in, int32_t n_in, void* d_t_out0, void* d_t_out1)
+{
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_over || !d_under) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch_partial_device: null output");
+    if (n_in < 0 || n_in > VP_MAX_RANKS || (n_in > 0 && !d_t_in)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_raymarch_partial_handoff_device: bad t_in");
+    VP_NO_FANOUT(c, "vp_raymarch_partial_device");
     int rc = ensure_device(c); if (rc) return rc;
     RmConsts k;
     rc = stage_raymarch(c, cam, rp, &k); if (rc) return rc;
@@ -564,15 +649,37 @@ VP_EXPORT int vp_raymarch_partial_device(vp_ctx* c, const vp_camera* cam, const 
     }
     float* keep = c->d_scene_depth;
     if (!rp->scene_depth && c->n_occluders == 0) c->d_scene_depth = nullptr;
-    rc = launch_raymarch(c, k, (float*)d_over, (float*)d_under);
+    RmHandoff ho{};
+    ho.t_in = n_in > 0 ? (const float*)d_t_in : nullptr; ho.n_in = n_in; ho.plane = (size_t)c->cfg.width * c->cfg.height;
+    ho.t_out0 = (float*)d_t_out0; ho.t_out1 = (float*)d_t_out1; ho.zsamples = c->d_zsamples;
+    VP_HIP(hipMemsetAsync(c->d_zsamples, 0, (size_t)c->g.Nz * sizeof(unsigned), c->stream));
+    rc = launch_raymarch(c, k, (float*)d_over, (float*)d_under, &ho);
     c->d_scene_depth = keep;
     return rc;
+}
+
+VP_EXPORT int vp_read_zsamples(vp_ctx* c, int64_t* samples_per_z)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (!samples_per_z) return vp_fail(c, VP_ERR_BAD_ARG, "vp_read_zsamples: null output");
+    VP_NO_FANOUT(c, "vp_read_zsamples");
+    int rc = ensure_device(c); if (rc) return rc;
+    { int rcs = stream_sync(c); if (rcs) return rcs; }
+    const int nz = c->g.Nz;
+    unsigned* h = (unsigned*)malloc((size_t)nz * sizeof(unsigned));
+    if (!h) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
+    hipError_t e = hipMemcpy(h, c->d_zsamples, (size_t)nz * sizeof(unsigned), hipMemcpyDeviceToHost);
+    for (int i = 0; i < nz; ++i) samples_per_z[i] = h[i];
+    free(h);
+    if (e != hipSuccess) return vp_fail(c, VP_ERR_HIP, "vp_read_zsamples: %s", hipGetErrorString(e));
+    return VP_OK;
 }
 
 VP_EXPORT int vp_blend_partials_device(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int32_t n, void* d_rgba_out)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_partials || !kinds || n < 0 || !d_rgba_out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_blend_partials_device: bad argument");
+    VP_NO_FANOUT(c, "vp_blend_partials_device");
     int rc = ensure_device(c); if (rc) return rc;
     return launch_blend(c, d_partials, kinds, n, (float*)d_rgba_out, (size_t)c->cfg.width * c->cfg.height);
 }
@@ -583,6 +690,7 @@ VP_EXPORT int vp_blend_partials_range_device(vp_ctx* c, const void* const* d_par
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_partials || !kinds || n < 0 || !d_rgba_out || num_pixels < 0)
         return vp_fail(c, VP_ERR_BAD_ARG, "vp_blend_partials_range_device: bad argument");
+    VP_NO_FANOUT(c, "vp_blend_partials_range_device");
     int rc = ensure_device(c); if (rc) return rc;
     return launch_blend(c, d_partials, kinds, n, (float*)d_rgba_out, (size_t)num_pixels);
 }
@@ -591,6 +699,8 @@ VP_EXPORT int vp_composite_device(vp_ctx* c, const void* d_particles_rgba, void*
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!d_particles_rgba || !d_scene_rgba) return vp_fail(c, VP_ERR_BAD_ARG, "vp_composite_device: null argument");
+    if (c->multi) c = multi_owner_of_slice(c, -1);               // the display rank's context (images live on its device)
+    if (!c) return VP_ERR_STATE;
     int rc = ensure_device(c); if (rc) return rc;
     return launch_composite(c, (const float*)d_particles_rgba, (float*)d_scene_rgba);
 }
@@ -599,6 +709,7 @@ VP_EXPORT int vp_z_boundary(vp_ctx* c, const vp_camera* cam, int32_t* zb)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!cam || !zb) return vp_fail(c, VP_ERR_BAD_ARG, "vp_z_boundary: null argument");
+    if (c->multi) c = multi_owner_of_slice(c, -2);               // any local child: the frame is the same everywhere
     if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_z_boundary before vp_set_frame");
     *zb = hl_z_boundary(c, cam);
     return VP_OK;
@@ -609,6 +720,7 @@ VP_EXPORT int vp_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (n < 0 || (n > 0 && !boxes)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders: bad argument");
+    if (c->multi) return multi_set_occluders(c, boxes, n);
     int rc = ensure_device(c); if (rc) return rc;
     if (n > c->occluders_cap) {
         if (c->d_occluders) VP_HIP(hipFree(c->d_occluders));
@@ -628,6 +740,7 @@ VP_EXPORT int vp_render_light_depth(vp_ctx* c, float light_near, float light_far
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!out || !(light_far > light_near)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_render_light_depth: bad argument");
+    if (c->multi) c = multi_owner_of_slice(c, -2);
     if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_render_light_depth before vp_set_frame");
     int rc = ensure_device(c); if (rc) return rc;
     float* d_tmp = nullptr;
@@ -646,6 +759,7 @@ VP_EXPORT int vp_render_scene_depth(vp_ctx* c, const vp_camera* cam, float* out)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!cam || !out) return vp_fail(c, VP_ERR_BAD_ARG, "vp_render_scene_depth: null argument");
+    if (c->multi) c = multi_owner_of_slice(c, -2);
     int rc = ensure_device(c); if (rc) return rc;
     const size_t n = (size_t)c->cfg.width * c->cfg.height;
     float* d_tmp = nullptr;
@@ -665,6 +779,7 @@ VP_EXPORT int vp_get_mv_positions(vp_ctx* c, float* out)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!out) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (c->multi) c = multi_owner_of_slice(c, -2);
     if (!c->have_frame) return vp_fail(c, VP_ERR_STATE, "vp_get_mv_positions before vp_set_frame");
     memcpy(out, c->h_mvPos, c->n3 * 3 * sizeof(float));
     return VP_OK;
@@ -674,6 +789,7 @@ VP_EXPORT int vp_read_bincounts(vp_ctx* c, int32_t* counts)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!counts) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (c->multi) return multi_read_bincounts(c, counts);
     if (!c->binned) return vp_fail(c, VP_ERR_STATE, "vp_read_bincounts before vp_bin");
     int rc = ensure_device(c); if (rc) return rc;
     { int rcs = stream_sync(c); if (rcs) return rcs; }
@@ -685,6 +801,7 @@ VP_EXPORT int vp_read_binlist(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, int
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!n || (cap > 0 && !ids)) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (c->multi) { vp_ctx* k = multi_owner_of_slice(c, zz); if (!k) return vp_fail(c, VP_ERR_BAD_ARG, "slice %d is not on this process", zz); c = k; }
     if (!c->binned) return vp_fail(c, VP_ERR_STATE, "vp_read_binlist before vp_bin");
     const GridConsts& g = c->g;
     if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
@@ -703,6 +820,7 @@ VP_EXPORT int vp_read_brick(vp_ctx* c, int32_t xx, int32_t yy, int32_t zz, uint1
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!half_rgba) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (c->multi) { vp_ctx* k = multi_owner_of_slice(c, zz); if (!k) return vp_fail(c, VP_ERR_BAD_ARG, "slice %d is not on this process", zz); c = k; }
     if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_read_brick before vp_fill");
     const GridConsts& g = c->g;
     if (xx < 0 || yy < 0 || zz < 0 || xx >= g.Nx || yy >= g.Ny || zz >= g.Nz) return vp_fail(c, VP_ERR_BAD_ARG, "MV index out of range");
@@ -737,6 +855,7 @@ VP_EXPORT int vp_read_lightmap(vp_ctx* c, float* out)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!out) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (c->multi) return multi_read_lightmap(c, out);
     if (!c->filled) return vp_fail(c, VP_ERR_STATE, "vp_read_lightmap before vp_fill");
     int rc = ensure_device(c); if (rc) return rc;
     { int rcs = stream_sync(c); if (rcs) return rcs; }
@@ -748,6 +867,7 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!st) return vp_fail(c, VP_ERR_BAD_ARG, "null output");
+    if (c->multi) return multi_get_stats(c, st);
     int rc = ensure_device(c); if (rc) return rc;
     memset(st, 0, sizeof *st);
     st->particles = c->P;
@@ -757,7 +877,7 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
         st->max_pairs_per_mv = c->h_meta.max_pairs;
         st->voxels_filled = (int64_t)c->h_meta.occupied * (int64_t)nv3(c);
     }
-    st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));      // pool as allocated (grey bricks use the first half of it)
+    st->brick_bytes = (int64_t)(c->brick_cap * nv3(c) * sizeof(uint2));      // pool as allocated (8 B/voxel in either storage format)
     st->brick_bytes_per_voxel = 8;
     st->brick_format = c->bricks_grey ? VP_BRICKS_GREY_ZPAIR : VP_BRICKS_RGBA16F;     // storage of the bricks as last filled
     { int rcs = stream_sync(c); if (rcs) return rcs; }
@@ -782,9 +902,30 @@ VP_EXPORT int vp_last_kernel_ms(vp_ctx* c, int32_t stage, float* ms)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!ms || stage < 0 || stage > 3) return vp_fail(c, VP_ERR_BAD_ARG, "vp_last_kernel_ms: bad argument");
+    if (c->multi) return multi_last_kernel_ms(c, stage, ms);
     if (!c->ev_valid[stage]) return vp_fail(c, VP_ERR_STATE, "stage %d has not run", stage);
     int rc = ensure_device(c); if (rc) return rc;
     VP_HIP(hipEventSynchronize(c->ev[stage][1]));
     VP_HIP(hipEventElapsedTime(ms, c->ev[stage][0], c->ev[stage][1]));
+    return VP_OK;
+}
+
+// ---- host-only planners (no device) --------------------------------------------------------------------------------------------------
+VP_EXPORT int vp_plan_slabs(int32_t nz, int32_t world, const double* fill_ms, const double* rm_ms, int32_t rm_groups, int32_t* cuts_out)
+{
+    if (nz < 1 || world < 1 || world > nz || world > VP_MAX_RANKS || !cuts_out)
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_plan_slabs: %d ranks for %d z-slices (at most one rank per slice, <= %d)", world, nz, VP_MAX_RANKS);
+    hl_plan_slabs(nz, world, fill_ms, rm_ms, rm_groups, cuts_out);
+    return VP_OK;
+}
+
+VP_EXPORT int vp_blend_plan(int32_t world, const int32_t* cuts, int32_t z_boundary, int32_t* chain_out, int32_t* plan_rank, int32_t* plan_which,
+                            int32_t* plan_kind, int32_t* n_plan, int32_t* straddler)
+{
+    if (world < 1 || world > VP_MAX_RANKS || !cuts || !chain_out || !plan_rank || !plan_which || !plan_kind || !n_plan)
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_blend_plan: bad argument");
+    for (int r = 0; r < world; ++r)
+        if (cuts[r] >= cuts[r + 1]) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_blend_plan: slab %d is empty", r);
+    *n_plan = hl_blend_plan(world, cuts, z_boundary, chain_out, plan_rank, plan_which, plan_kind, straddler);
     return VP_OK;
 }

@@ -34,6 +34,13 @@
 #endif
 #define VPFX_STR2(x) #x
 #define VPFX_STR(x) VPFX_STR2(x)
+// A/B: fetch the bilinear quad as TWO 16-bit reads (x-adjacent texels are adjacent bytes; every other address is odd: LDS takes
+// unaligned 16-bit reads) instead of four byte reads, converted with v_cvt_f32_ubyte0/1 from the same register.  Halves the LDS
+// instructions (and their 3-4-way bank conflicts); the VALU count is unchanged.
+#ifndef VPFX_LDS_U16
+#define VPFX_LDS_U16 0
+#endif
+#define VPFX_LDS_READS (VPFX_LDS_U16 ? 2 : 4)      // LDS instructions per slice (lgkmcnt bookkeeping)
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
 #endif
@@ -134,7 +141,8 @@ __device__ __forceinline__ void wait_lgkm(QuadU8& q)
 template <int D>
 __device__ __forceinline__ void wait_lgkm_dyn(int i, QuadU8& q)
 {
-    if (D - 1 - i >= 3) wait_lgkm<12>(q); else if (D - 1 - i == 2) wait_lgkm<8>(q); else if (D - 1 - i == 1) wait_lgkm<4>(q); else wait_lgkm<0>(q);
+    constexpr int R = VPFX_LDS_READS;
+    if (D - 1 - i >= 3) wait_lgkm<3 * R>(q); else if (D - 1 - i == 2) wait_lgkm<2 * R>(q); else if (D - 1 - i == 1) wait_lgkm<R>(q); else wait_lgkm<0>(q);
 }
 
 template <bool EXACT>
@@ -165,7 +173,13 @@ struct FillPtrs {
 // memory access (the cubemap footprint) can be in flight while the next slice is being addressed:
 //   stage 1: texCUBE addressing  -> footprint index + bilinear weights
 //   stage 2: bilinear + displacement + smoothstep -> (density contribution, net displacement)
-template <bool EXACT, int TAB>
+// DONE (displacement scale exactly 1, default math): net displacement == the filtered texel, and the reference's smoothstep(net, 0.7 net, x)
+// jumps at net == 0 (x / +0 -> 1, but 0 for any net > 0).  Whether a bilinear weight is EXACTLY 0 then decides between no density and full
+// density, so the in-face coordinates must not come out on the other side of an integer than the oracle's.  The reciprocal-based
+// coordinates are off by <= ~3e-5; whenever some lane's coordinate lies within 1e-4 of an integer (2.6 % of the wave-slices) the wave
+// recomputes them with the oracle's IEEE arithmetic, and the weights are fx - floor(fx) like the oracle's (zero iff fx is an integer).
+// Everything else stays on the fast path: <= 1 fp16 ulp like every default-math fill, but no voxel flips sides of the jump.
+template <bool EXACT, int TAB, bool DONE>
 __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx, float psy, float psz, float& tx, float& ty, float lds_bias)
 {
     // D3D cube-face selection with the CDNA cube-map VALU instructions (v_cubeid/sc/tc/ma_f32): face id, the two in-face
@@ -187,14 +201,26 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
         // give the face centre like the EXACT branch), one FMA per axis
         const float invS = Sf * __builtin_amdgcn_rcpf(ma2 + 1.0e-30f);     // + 1e-30: bit-neutral for any real direction, keeps 1/0 finite
         fx = fmaf(sc, invS, f.half_s_m05); fy = fmaf(tc, invS, f.half_s_m05);
+        if (DONE) {
+            const float wx = fx - floorf(fx), wy = fy - floorf(fy);
+            const bool near_int = fminf(wx, wy) < 1.0e-4f || fmaxf(wx, wy) > 1.0f - 1.0e-4f;
+            if (__builtin_amdgcn_ballot_w64(near_int)) {                   // wave-uniform, rare
+                float uh = 0.f, vh = 0.f;
+                if (ma2 > 0.f) { const float inv = 1.0f / ma2; uh = sc * inv; vh = tc * inv; }
+                fx = fmaf(uh, Sf, f.half_s_m05); fy = fmaf(vh, Sf, f.half_s_m05);
+            }
+        }
     }
     const float x0 = floorf(fx), y0 = floorf(fy);
     // EXACT keeps the oracle's fx - floor(fx); the fast path uses v_fract_f32 (identical except that a weight that
     // would round up to exactly 1.0 is returned as the largest float below 1).  (Measured without gain, bit-identical bricks: the
     // subtract in the fast path too -- it costs two registers more and with them two spills --, the index as fx - fract(fx) instead of
     // v_floor, the slice index advanced by adds instead of converted.)
-    tx = EXACT ? fx - x0 : __builtin_amdgcn_fractf(fx);
-    ty = EXACT ? fy - y0 : __builtin_amdgcn_fractf(fy);
+#ifndef VPFX_W_SUB
+#define VPFX_W_SUB 0     // A/B: weights by subtraction (full-rate v_sub instead of v_fract) on the default path too
+#endif
+    tx = (EXACT || DONE || VPFX_W_SUB) ? fx - x0 : __builtin_amdgcn_fractf(fx);
+    ty = (EXACT || DONE || VPFX_W_SUB) ? fy - y0 : __builtin_amdgcn_fractf(fy);
     // |sc|, |tc| <= |major|, so fx, fy lie in [-0.5, S - 0.5] (up to the reciprocal's last ulp) and floor() in [-1, S - 1]:
     // the clamp-addressing of the footprint table never needs a min/max here.  The BYTE offset of the column pair,
     // 8 ((face (S+1) + y0 + 1)(S+2) + x0 + 1), is formed in float as three FMAs (exact: small integers) + one conversion.
@@ -206,7 +232,7 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     return (unsigned)fmaf(fid, S2f * pf, fmaf(y0, pf, x0 + lds_bias));
 }
 
-template <bool EXACT>
+template <bool EXACT, bool DONE>
 __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
                                            const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
                                            float d2, float opw, float& den, float& net, float Dk /* D, or D/255 for byte texels */,
@@ -222,14 +248,12 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
         t = fminf(fmaxf(t, 0.f), 1.f);
     } else {
         // same quantity, (4 d2 - net) / (-0.3 net) = 10/3 - (40/3) d2 / net, as reciprocal + multiply + fused clamp.  One input
-        // needs the quotient form: displacement scale exactly 1 makes net == 0 on a zero texel, where the reference's
+        // needs the quotient form: displacement scale exactly 1 (DONE) makes net == 0 on a zero texel, where the reference's
         // (x - net) / (0.7 net - net) is x / +0 = +inf -> saturate 1 (density = opacityFactor; 0 / 0 saturates to 0) while
-        // 10/3 - (40/3) d2 / 0 would give 0.  (4 d2 - net) * rcp(fma(net, 0.7, -net)) keeps the sign of that zero; it costs 3 % of
-        // the kernel, so it is only taken when D == 1 (a wave-uniform integer flag: scalar compare + branch).  (launch_fill now sends D == 1
-        // fills to the EXACT kernels altogether -- the in-face coordinates have to be exact there as well --, so this branch is a safety net;
-        // without it the default path measured 1 % SLOWER, an artefact of instruction scheduling.)
+        // 10/3 - (40/3) d2 / 0 would give 0.  (4 d2 - net) * rcp(fma(net, 0.7, -net)) keeps the sign of that zero (+3 % of the kernel:
+        // compiled into the D == 1 kernels only).
         // (the saturate rides on the producing instruction's clamp bit; hipcc otherwise spends a v_max_f32 ... clamp after a literal-form FMA)
-        if (f.d_is_one) {
+        if (DONE) {
             const float num = fmaf(d2, 4.0f, -net), rden = __builtin_amdgcn_rcpf(fmaf(net, 0.7f, -net));
             asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(t) : "v"(num), "v"(rden));
         } else {
@@ -291,11 +315,14 @@ __device__ __forceinline__ void chain_publish(unsigned long long* w, float v, ui
 // axis zz = z0 .. z1.  TAB = 0: cube-map footprints from the global f32 pair table (p_cubequads);  TAB = 1 / 2: R8 cube map
 // resident in LDS (1: S = 128, row pitch 130 as instruction immediates; 2: any S, pitch from FillConsts).
 // CHAIN: only metavoxel zz_a of the column, light handed on through `ch` (see FillChain); otherwise zz_a .. zz_b - 1 with the light in a register.
-template <int NV, bool EXACT, int MODE, int TAB, bool CHAIN = false>
+// MATH: 0 = default (v_rcp_f32 in the covered-voxel math), 1 = EXACT (IEEE divisions: bricks bit-identical to the oracle), 2 = default math
+// for displacement scale exactly 1 (DONE, see cube_address).
+template <int NV, int MATH, int MODE, int TAB, bool CHAIN = false>
 __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts& f, FILL_PTR_PARAMS, const int xx, const int yy, const int px,
                                           const int py, const int lane, const unsigned lds_base, const int zz_a, const int zz_b,
                                           const FillChain ch = FillChain{})
 {
+    constexpr bool EXACT = MATH == 1, DONE = MATH == 2;
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
     constexpr int PIPE = TAB == 0 ? VPFX_FILL_PIPE : VPFX_FILL_PIPE_LDS;   // footprint loads in flight per wave
     static_assert(TAB == 0 || !EXACT, "the LDS (R8) path is default-math only: EXACT keeps the oracle's f32 table arithmetic");
@@ -425,19 +452,30 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     const float psx = fmaf(fs, Bx, Ax), psy = fmaf(fs, By, Ay), psz = fmaf(fs, Bz, Az);
                     d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
                     hit = d2 <= 0.25f;                                                   // Fill.shader:172,196
-                    const unsigned qi = cube_address<EXACT, TAB>(f, psx, psy, psz, tx, ty, lds_bias);
+                    const unsigned qi = cube_address<EXACT, TAB, DONE>(f, psx, psy, psz, tx, ty, lds_bias);
                     if constexpr (TAB == 0) {
                         const unsigned off = hit ? qi : 0u;                              // byte offset into the footprint table
                         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
                     } else if constexpr (TAB == 1) {
                         const unsigned off = qi;   // every lane reads: any direction addresses inside the table (a select for the lanes without a covered voxel cost more)
+#if VPFX_LDS_U16
+                        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:" VPFX_STR(VPFX_LDS_PITCH_128)
+                                     : "=&v"(q.a), "=&v"(q.b) : "v"(off) : "memory");
+                        q.c = q.d = 0;
+#else
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "+1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
+#endif
                     } else {
                         const unsigned off = hit ? qi : lds_base;
                         const unsigned off2 = off + (unsigned)f.lds_pitch;                // the row below
+#if VPFX_LDS_U16
+                        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3" : "=&v"(q.a), "=&v"(q.b) : "v"(off), "v"(off2) : "memory");
+                        q.c = q.d = 0;
+#else
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %5\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %5 offset:1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off), "v"(off2) : "memory");
+#endif
                     }
                 };
                 auto stage2 = [&](int s, float tx, float ty, float d2, bool hit, const Q& q) {
@@ -445,8 +483,12 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         float den, net;
                         float4 qf;
                         if constexpr (TAB == 0) qf = make_float4(q[0], q[1], q[2], q[3]);
+#if VPFX_LDS_U16
+                        else qf = make_float4((float)(q.a & 0xffu), (float)(q.b & 0xffu), (float)((q.a >> 8) & 0xffu), (float)((q.b >> 8) & 0xffu));   // v_cvt_f32_ubyte0 / 1
+#else
                         else qf = make_float4((float)q.a, (float)q.b, (float)q.c, (float)q.d);   // bytes 0..255; 1/255 is folded into Dk
-                        cube_shade<EXACT>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
+#endif
+                        cube_shade<EXACT, DONE>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
 #if VPFX_FILL_LDS_TILE == 1
                         lds_dens[s * 64] += den;                                         // ds_read_b32, v_add_f32, ds_write_b32
                         atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));   // ds_max_i32
@@ -470,7 +512,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     for (int i = 0; i < D; ++i) stage1(s + i, tx[i], ty[i], d2[i], hit[i], q[i]);
 #pragma unroll
                     for (int i = 0; i < D; ++i) {
-                        if constexpr (TAB == 0) wait_vm<D - 1>(q[i]); else wait_lgkm<4 * (D - 1)>(q[i]);
+                        if constexpr (TAB == 0) wait_vm<D - 1>(q[i]); else wait_lgkm<VPFX_LDS_READS * (D - 1)>(q[i]);
                         stage2(s + i, tx[i], ty[i], d2[i], hit[i], q[i]);
                         stage1(s + D + i, tx[i], ty[i], d2[i], hit[i], q[i]);
                     }
@@ -557,7 +599,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 // taken from a counter when the workgroup STARTS (not from blockIdx: nothing guarantees dispatch order), so a unit's producer always
 // started before it.  Otherwise one workgroup walks the tile's whole column (the per-metavoxel entry point, whose light goes through the
 // light map like the reference's UAV).
-template <int NV, bool EXACT, int MODE, bool CHAIN>
+template <int NV, int MATH, int MODE, bool CHAIN>
 __global__ void __launch_bounds__(256, VPFX_FILL_WAVES)
 k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restrict__ p_counter)
 {
@@ -577,11 +619,11 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restric
     if (CHAIN) {
         const int mi = ch.occ_list[unit / TPM];
         const int nxy = g.Nx * g.Ny, zz = mi / nxy, col = mi - zz * nxy;
-        fill_tile<NV, EXACT, MODE, 0, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
+        fill_tile<NV, MATH, MODE, 0, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
                                             p_light_out, p_bricks, p_dens_ao, p_ws, col % g.Nx, col / g.Nx, px, py, lane, 0u, zz, zz + 1, ch);
     } else {
         const int col = p_colorder[unit / TPM];
-        fill_tile<NV, EXACT, MODE, 0>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
+        fill_tile<NV, MATH, MODE, 0>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap, p_light_in,
                                       p_light_out, p_bricks, p_dens_ao, p_ws, col % g.Nx, col / g.Nx, px, py, lane, 0u, g.z0, g.z1);
     }
 }
@@ -591,7 +633,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restric
 // arithmetic, is what k_fill waits for (one wave-wide divergent load per covered slice through the CU's single L1/TA path).
 // One PERSISTENT workgroup of 16 waves per CU (4 per SIMD) loads the table once; every wave then pulls (metavoxel, 8x8-column tile)
 // units from a global work counter on its own.
-template <int NV, int MODE, int TAB>
+template <int NV, int MODE, int TAB, bool DONE>
 __global__ void __launch_bounds__(64 * VPFX_FILL_LDS_WAVES)
 k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
            int nitems, FillChain ch)
@@ -613,7 +655,7 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
         const int mi = ch.occ_list[item / TPC];
         const int nxy = g.Nx * g.Ny, zz = mi / nxy, col = mi - zz * nxy;
         const int xx = col % g.Nx, yy = col / g.Nx;
-        fill_tile<NV, false, MODE, TAB, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap,
+        fill_tile<NV, DONE ? 2 : 0, MODE, TAB, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap,
                                               p_light_in, p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, zz, zz + 1, ch);
     }
 }
@@ -740,7 +782,7 @@ k_build_cube_u8(const uint8_t* __restrict__ cube, int S, int pitch, uint8_t* __r
     out[i] = v;
 }
 
-// dynamic LDS above 64 KB has to be granted per kernel once
+// dynamic LDS above 64 KB has to be granted per kernel (and per device)
 template <typename K>
 int allow_big_lds(vp_ctx* c, K kernel, size_t bytes)
 {
@@ -764,7 +806,7 @@ int chain_begin(vp_ctx* c, const FillPtrs& P, int mode, FillChain& ch)
         c->chain_seq = 0;
     }
     ch.words = c->d_chain; ch.ord = c->d_ord; ch.colcount = c->d_colcount; ch.occ_list = c->d_occ_list; ch.error = c->d_chain_err;
-    const bool hook = c->cfg.reserved[2] == VPFX_CFG_TEST_CHAIN_TIMEOUT;
+    const bool hook = c->test_chain_timeout;                 // VPFX_TEST_CHAIN_TIMEOUT=1 in the environment at vp_create (watchdog test)
     ch.spin_limit = hook ? 64u : VPFX_CHAIN_SPIN_LIMIT;
     ch.wait_bias = hook ? 0x40000000u : 0u;
     ch.tag_base = c->chain_seq * span;
@@ -772,13 +814,14 @@ int chain_begin(vp_ctx* c, const FillPtrs& P, int mode, FillChain& ch)
     return VP_OK;
 }
 
-template <int NV, int MODE, int TAB>
+template <int NV, int MODE, int TAB, bool DONE>
 int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
 {
     const size_t bytes = cube_u8_bytes(c->cube_u8_S);
-    auto kernel = k_fill_lds<NV, MODE, TAB>;
-    static bool granted = false;                      // per instantiation (the attribute sticks to the function)
-    if (!granted) { int rc = allow_big_lds(c, kernel, 160 * 1024); if (rc) return rc; granted = true; }
+    auto kernel = k_fill_lds<NV, MODE, TAB, DONE>;
+    // dynamic LDS above 64 KB is an opt-in per kernel AND per device: asked for before every launch (a cached "granted" flag would be
+    // per process, and a host driving several GPUs launches the same instantiation on each of them)
+    { int rc = allow_big_lds(c, kernel, 160 * 1024); if (rc) return rc; }
     constexpr int TPC = (NV / 8) * (NV / 8);
     FillChain ch{};
     const int nitems = c->h_meta.occupied * TPC;
@@ -792,16 +835,25 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     return VP_OK;
 }
 
-template <int NV>
+template <int NV, bool DONE>
 int launch_fill_lds_nv(vp_ctx* c, int mode, const FillPtrs& P)
 {
     const bool s128 = c->cube_u8_S == 128;
-    if (mode == 0) return s128 ? launch_fill_lds_variant<NV, 0, 1>(c, P) : launch_fill_lds_variant<NV, 0, 2>(c, P);
-    return s128 ? launch_fill_lds_variant<NV, 1, 1>(c, P) : launch_fill_lds_variant<NV, 1, 2>(c, P);
+    if (mode == 0) return s128 ? launch_fill_lds_variant<NV, 0, 1, DONE>(c, P) : launch_fill_lds_variant<NV, 0, 2, DONE>(c, P);
+    return s128 ? launch_fill_lds_variant<NV, 1, 1, DONE>(c, P) : launch_fill_lds_variant<NV, 1, 2, DONE>(c, P);
+}
+
+template <int NV, int MATH>
+int launch_fill_chain(vp_ctx* c, int mode, const FillPtrs& P, const FillChain& ch, dim3 grid, int tl)
+{
+    const dim3 block(256);
+    if (mode == 0) hipLaunchKernelGGL((k_fill<NV, MATH, 0, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
+    else           hipLaunchKernelGGL((k_fill<NV, MATH, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
+    return VP_OK;
 }
 
 template <int NV>
-int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
+int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, int math)
 {
     constexpr int TPM = (NV / 16) * (NV / 16);
     const dim3 block(256);
@@ -816,14 +868,8 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, bool exact)
     const dim3 grid(c->h_meta.occupied * TPM);
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     const int tl = VPFX_FILL_LDS_TILE ? 4 * 2 * (NV < 32 ? NV : 32) * 64 * (int)sizeof(float) : 0;    // A/B variant: the four waves' (density, ao) tiles
-    if (mode == 0) {
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
-        else       hipLaunchKernelGGL((k_fill<NV, false, 0, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
-    } else {
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
-        else       hipLaunchKernelGGL((k_fill<NV, false, 1, true>), grid, block, tl, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), ch, c->d_work_counter);
-    }
-    return VP_OK;
+    return math == 1 ? launch_fill_chain<NV, 1>(c, mode, P, ch, grid, tl) : math == 2 ? launch_fill_chain<NV, 2>(c, mode, P, ch, grid, tl)
+                                                                                     : launch_fill_chain<NV, 0>(c, mode, P, ch, grid, tl);
 }
 
 }  // namespace
@@ -872,13 +918,14 @@ int launch_fill_one(vp_ctx* c, int xx, int yy, int zz)
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
     GridConsts g = c->g;
     g.z0 = zz; g.z1 = zz + 1;
-    const bool exact = c->cfg.exact_math == 1 || c->fc.d_is_one != 0;      // see launch_fill
+    const int math = c->cfg.exact_math == 1 ? 1 : c->fc.d_is_one ? 2 : 0;  // see launch_fill
     const dim3 block(256);
 #define VPFX_FILL_ONE(NV)                                                                                            \
     do {                                                                                                              \
         const dim3 grid((NV / 16) * (NV / 16));                                                                       \
-        if (exact) hipLaunchKernelGGL((k_fill<NV, true, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr);  \
-        else       hipLaunchKernelGGL((k_fill<NV, false, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr); \
+        if (math == 1)      hipLaunchKernelGGL((k_fill<NV, 1, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr);  \
+        else if (math == 2) hipLaunchKernelGGL((k_fill<NV, 2, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr);  \
+        else                hipLaunchKernelGGL((k_fill<NV, 0, 0, false>), grid, block, 0, c->stream, g, c->fc, FILL_PTR_ARGS(P), FillChain{}, (int*)nullptr);  \
     } while (0)
     switch (c->g.nv) {
     case 16: VPFX_FILL_ONE(16); break;
@@ -888,8 +935,7 @@ int launch_fill_one(vp_ctx* c, int xx, int yy, int zz)
     }
 #undef VPFX_FILL_ONE
     VP_HIP(hipGetLastError());
-    c->bricks_grey = c->fc.grey != 0;
-    return VP_OK;
+    return VP_OK;      // (the pool's format is fixed by vp_fill_begin: c->fc.grey == c->bricks_grey here)
 }
 
 int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out)
@@ -900,20 +946,21 @@ int launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out
     P.depthmap = c->have_depthmap ? c->d_depthmap : nullptr;
     P.light_in = d_light_in; P.light_out = d_light_out;
     P.bricks = c->d_bricks; P.dens_ao = c->d_dens_ao; P.ws = c->d_ws;
-    // IEEE divisions everywhere: parity builds -- and a displacement scale of exactly 1, where net displacement == texel and the reference's
-    // smoothstep(net, 0.7 net, x) jumps at net == 0 (x / +0 -> 1, but 0 for any net > 0): whether a bilinear weight is EXACTLY 0 then decides
-    // between no density and full density, so reciprocal-based in-face coordinates flip a voxel now and then (fuzz-found: three scenes in
-    // 14 000 with white-noise maps).  Those fills take the bit-exact kernels (about twice the time).
-    const bool exact = c->cfg.exact_math == 1 || c->fc.d_is_one != 0;
+    // math: 1 = IEEE divisions everywhere (parity builds, float table only); 2 = displacement scale exactly 1, where net displacement
+    // == texel and the reference's smoothstep(net, 0.7 net, x) jumps at net == 0: default math with the flip-deciding quantities exact
+    // (cube_address; round 2 sent these fills to the EXACT kernels at about twice the time); 0 = default.
+    const int math = c->cfg.exact_math == 1 ? 1 : c->fc.d_is_one ? 2 : 0;
     // R8 cube map resident as a byte table that fits LDS: the persistent LDS kernel (default math only; EXACT keeps the f32 table)
-    const bool lds = mode != 2 && !exact && c->cube_u8_S > 0 && c->cube_u8_S == c->cubeS && c->cfg.reserved[0] != VPFX_CFG_NO_LDS_CUBEMAP;
+    const bool lds = mode != 2 && math != 1 && c->cube_u8_S > 0 && c->cube_u8_S == c->cubeS && c->cfg.reserved[0] != VPFX_CFG_NO_LDS_CUBEMAP;
     const int evi = mode == 2 ? 3 : 1;
     VP_HIP(hipEventRecord(c->ev[evi][0], c->stream));
     int rc = VP_OK;
     switch (c->g.nv) {
-    case 16: rc = lds ? launch_fill_lds_nv<16>(c, mode, P) : launch_fill_nv<16>(c, mode, P, exact); break;
-    case 32: rc = lds ? launch_fill_lds_nv<32>(c, mode, P) : launch_fill_nv<32>(c, mode, P, exact); break;
-    case 64: rc = lds ? launch_fill_lds_nv<64>(c, mode, P) : launch_fill_nv<64>(c, mode, P, exact); break;
+#define VPFX_FILL_NV(NV) rc = !lds ? launch_fill_nv<NV>(c, mode, P, math) : math == 2 ? launch_fill_lds_nv<NV, true>(c, mode, P) : launch_fill_lds_nv<NV, false>(c, mode, P)
+    case 16: VPFX_FILL_NV(16); break;
+    case 32: VPFX_FILL_NV(32); break;
+    case 64: VPFX_FILL_NV(64); break;
+#undef VPFX_FILL_NV
     default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", c->g.nv);
     }
     if (rc) return rc;

@@ -207,3 +207,110 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
     k->inv_soft = 1.0f / (float)rp->soft_distance;                           // rcp(_SoftDistance)       RM.shader:269
     k->alpha_cutoff = 0.0f;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Multi-GPU host logic: the slab cut and the compositing order of the slabs (no device work; exported through vp_plan_slabs /
+// vp_blend_plan so that it is testable without a GPU).
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// Optimal contiguous partition of w[0..nz) into `world` slabs of >= 1 slice each, minimising the heaviest slab (exact min-max DP;
+// nz <= a few hundred, world <= 16).  Ties go to the cut whose last slab is closest to the uniform thickness, so a flat histogram gives
+// uniform slabs.
+void min_max_partition(int nz, int world, const std::vector<double>& w, int* cuts)
+{
+    std::vector<double> pre(nz + 1, 0.0);
+    for (int z = 0; z < nz; ++z) pre[z + 1] = pre[z] + std::max(w[z], 0.0);
+    if (!(pre[nz] > 0.0)) {                                  // no work anywhere: uniform
+        for (int i = 0; i <= world; ++i) cuts[i] = (int)std::lround((double)i * nz / world);
+        return;
+    }
+    const double INF = 1e300, uni = (double)nz / world;
+    std::vector<std::vector<double>> dp(world + 1, std::vector<double>(nz + 1, INF));
+    std::vector<std::vector<int>> arg(world + 1, std::vector<int>(nz + 1, 0));
+    dp[0][0] = 0.0;
+    for (int k = 1; k <= world; ++k)
+        for (int z = k; z <= nz - (world - k); ++z) {
+            double best = INF;
+            int besty = k - 1;
+            for (int y = k - 1; y < z; ++y) {                // last slab = [y, z)
+                if (dp[k - 1][y] >= INF) continue;
+                const double v = std::max(dp[k - 1][y], pre[z] - pre[y]);
+                if (v < best || (v == best && std::fabs((z - y) - uni) < std::fabs((z - besty) - uni))) { best = v; besty = y; }
+            }
+            dp[k][z] = best; arg[k][z] = besty;
+        }
+    int z = nz;
+    cuts[world] = nz;
+    for (int k = world; k >= 1; --k) { z = arg[k][z]; cuts[k - 1] = z; }
+}
+
+}  // namespace
+
+void hl_chain_groups(int world, int rm_groups, int* group_of_pos)
+{
+    const int G = std::min(std::max(rm_groups, 1), world);
+    for (int p = 0; p < world; ++p) group_of_pos[p] = (int)(((long long)p * G) / world);
+}
+
+// The frame waits for the slowest slab in the fill (x 1.3: local pass + finish pass of the split fill) and, in the ray-march, for the
+// slowest slab of every hand-off group in turn (groups run one after the other; within a group the slabs march concurrently).  The cut
+// that balances fill + ray-march per slice need not minimise that, so the candidates are the optimal min-max partitions of
+// fill + alpha * raymarch for a few alpha (0 = fill only ... raymarch only) and the one with the smallest modelled frame wins (ties: the
+// earliest candidate, i.e. the more fill-balanced).  Groups are taken in rank order here (exact for a camera outside the grid along the
+// light axis, the benchmark's case; a camera inside the grid reorders the chain around the straddling slab).
+void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms, int rm_groups, int* cuts)
+{
+    if (world > nz) world = nz;
+    std::vector<double> w(nz, 1.0);
+    if (!fill_ms && !rm_ms) { min_max_partition(nz, world, w, cuts); return; }
+    std::vector<int> gp(world);
+    hl_chain_groups(world, rm_groups, gp.data());
+    const double alphas[] = {0.0, 0.25, 0.5, 1.0, 2.0, 4.0, -1.0};
+    double best_t = 1e300;
+    std::vector<int> cand(world + 1);
+    bool have = false;
+    for (double a : alphas) {
+        for (int z = 0; z < nz; ++z) {
+            const double f = fill_ms ? fill_ms[z] : 0.0, r = rm_ms ? rm_ms[z] : 0.0;
+            w[z] = a < 0.0 ? r : f + a * r;
+        }
+        min_max_partition(nz, world, w, cand.data());
+        double fmax = 0.0;
+        std::vector<double> gmax(world, 0.0);
+        for (int r = 0; r < world; ++r) {
+            double f = 0.0, m = 0.0;
+            for (int z = cand[r]; z < cand[r + 1]; ++z) { f += fill_ms ? fill_ms[z] : 0.0; m += rm_ms ? rm_ms[z] : 0.0; }
+            fmax = std::max(fmax, f);
+            gmax[gp[r]] = std::max(gmax[gp[r]], m);
+        }
+        double t = 1.3 * fmax;
+        for (double g : gmax) t += g;
+        if (!have || t < best_t - 1e-12) { best_t = t; have = true; for (int i = 0; i <= world; ++i) cuts[i] = cand[i]; }
+    }
+}
+
+// RenderMetavoxels at slab granularity (VPR.cs:652-711): phase A = slabs with slices zz <= zBoundary, zz ascending, blended OVER; phase B =
+// slabs with slices zz > zBoundary, zz ascending, blended UNDER; the one slab that straddles zBoundary has an image in either phase.
+// plan = the partial images in the reference's blend order.  chain = the same slabs FRONT TO BACK (reverse of phase A, then phase B):
+// every slab earlier in the chain is composited in front of every later one -- for a phase-A slab behind the straddler only the
+// straddler's phase-A image counts (its phase-B image is behind all of phase A).
+int hl_blend_plan(int world, const int* cuts, int zb, int* chain, int* plan_rank, int* plan_which, int* plan_kind, int* straddler)
+{
+    int n = 0, strad = -1;
+    for (int r = 0; r < world; ++r)
+        if (cuts[r] <= zb) { plan_rank[n] = r; plan_which[n] = 0; plan_kind[n] = 0; ++n; }
+    for (int r = 0; r < world; ++r) {
+        const bool has_a = cuts[r] <= zb, has_b = cuts[r + 1] - 1 > zb;
+        if (has_b) { plan_rank[n] = r; plan_which[n] = has_a ? 1 : 0; plan_kind[n] = 1; ++n; }
+        if (has_a && has_b) strad = r;
+    }
+    int p = 0;
+    if (strad >= 0) chain[p++] = strad;
+    for (int r = world - 1; r >= 0; --r)
+        if (cuts[r] <= zb && r != strad) chain[p++] = r;      // phase-A-only slabs, nearest the camera (highest zz) first
+    for (int r = 0; r < world; ++r)
+        if (cuts[r + 1] - 1 > zb && r != strad) chain[p++] = r;
+    if (straddler) *straddler = strad;
+    return n;
+}

@@ -433,11 +433,15 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
 #ifndef VPFX_RM_WAVES_GREY
 #define VPFX_RM_WAVES_GREY 5      // the grey-brick kernels without flag paths need 95 VGPRs (whole grid and slab): 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3)
 #endif
+// (RmHandoff: vpfx_internal.h)
+#define VPFX_RM_HANDOFF_CUTOFF 2.98023224e-8f          // 2^-25
+
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY>
 __global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL : (GREY && !FLAGS) ? VPFX_RM_WAVES_GREY : VPFX_RM_WAVES)
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
-           unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out)
+           unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out,
+           RmHandoff ho)
 {
     const int lane = threadIdx.x;
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
@@ -494,6 +498,12 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     }
     const int nxy = k.Nx * k.Ny;
     bool done = !(tg0 <= tg1);
+    float tin = 1.0f, aA = 0.f;
+    const float cutoff = (PARTIAL && ho.t_in) ? VPFX_RM_HANDOFF_CUTOFF : k.alpha_cutoff;
+    if (PARTIAL && ho.t_in) {
+        for (int j = 0; j < ho.n_in; ++j) tin *= ho.t_in[(size_t)j * ho.plane + pi];
+        if (early_out && tin <= cutoff) done = true;           // hidden by the slabs in front before this one starts
+    }
 
     // Slab order.  The reference draws phase A (zz <= zBoundary) zz ascending, cells far -> near, blended OVER, then phase B
     // (zz > zBoundary) zz ascending, cells near -> far, blended UNDER (VPR.cs:652-711): front to back that is the REVERSE of
@@ -519,6 +529,8 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         const bool over = FLAGS && phaseA;                                                 // literal OVER, cells far -> near
         if (PARTIAL && !phaseA && !storedA) {
             img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+            aA = dst.w;
+            tin *= 1.0f - dst.w;                               // the slab's own phase-A image hides its phase-B image too
             dst = F4{0.f, 0.f, 0.f, 0.f};
             storedA = true;
         }
@@ -613,7 +625,10 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         // saturated: everything farther along the ray is multiplied by (1 - dst.a) == 0.  (A saturated phase-A image of a slab
         // also hides the slab's own phase-B image, which is composited behind it.)
         dst = d;
-        if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
+        if (PARTIAL) {
+            if (!over && early_out && (1.0f - d.w) * tin <= cutoff) done = true;
+            if (ho.zsamples && nsamp != ns_start) atomicAdd(ho.zsamples + zz, (unsigned)(nsamp - ns_start));   // uniform address: one atomic per wave
+        } else if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
     }
 
     if (PARTIAL && storedA) {
@@ -621,6 +636,11 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     } else {
         img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
         if (PARTIAL) img_under[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (PARTIAL && ho.t_out0) {
+        const float t0 = storedA ? 1.0f - aA : 1.0f - dst.w;
+        ho.t_out0[pi] = t0;
+        if (ho.t_out1) ho.t_out1[pi] = storedA ? t0 * (1.0f - dst.w) : t0;
     }
     if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
 }
@@ -711,7 +731,7 @@ k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, si
 }
 
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY = false>
-void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
+void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
 {
     const int nsuper = rm_num_super_tiles(k.W, k.H);
     const int* order = nullptr;
@@ -725,39 +745,40 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
 #endif
     const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
     hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS, GREY>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
-                       c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out);
+                       c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out, ho);
 }
 
 template <int NV>
-void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out)
+void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
 {
     const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
     const int sel = (d_under ? 4 : 0) | (wrap ? 2 : 0) | (k.flags ? 1 : 0);
     if (c->bricks_grey) {                  // (luminance, density) bricks: only ever filled with border >= 1
         switch (sel & 5) {
-        case 0: launch_rm_variant<NV, false, false, false, true>(c, k, d_over, d_under, early_out); break;
-        case 1: launch_rm_variant<NV, false, false, true, true>(c, k, d_over, d_under, early_out); break;
-        case 4: launch_rm_variant<NV, true, false, false, true>(c, k, d_over, d_under, early_out); break;
-        default: launch_rm_variant<NV, true, false, true, true>(c, k, d_over, d_under, early_out); break;
+        case 0: launch_rm_variant<NV, false, false, false, true>(c, k, d_over, d_under, early_out, ho); break;
+        case 1: launch_rm_variant<NV, false, false, true, true>(c, k, d_over, d_under, early_out, ho); break;
+        case 4: launch_rm_variant<NV, true, false, false, true>(c, k, d_over, d_under, early_out, ho); break;
+        default: launch_rm_variant<NV, true, false, true, true>(c, k, d_over, d_under, early_out, ho); break;
         }
         return;
     }
     switch (sel) {
-    case 0: launch_rm_variant<NV, false, false, false>(c, k, d_over, d_under, early_out); break;
-    case 1: launch_rm_variant<NV, false, false, true>(c, k, d_over, d_under, early_out); break;
-    case 2: launch_rm_variant<NV, false, true, false>(c, k, d_over, d_under, early_out); break;
-    case 3: launch_rm_variant<NV, false, true, true>(c, k, d_over, d_under, early_out); break;
-    case 4: launch_rm_variant<NV, true, false, false>(c, k, d_over, d_under, early_out); break;
-    case 5: launch_rm_variant<NV, true, false, true>(c, k, d_over, d_under, early_out); break;
-    case 6: launch_rm_variant<NV, true, true, false>(c, k, d_over, d_under, early_out); break;
-    default: launch_rm_variant<NV, true, true, true>(c, k, d_over, d_under, early_out); break;
+    case 0: launch_rm_variant<NV, false, false, false>(c, k, d_over, d_under, early_out, ho); break;
+    case 1: launch_rm_variant<NV, false, false, true>(c, k, d_over, d_under, early_out, ho); break;
+    case 2: launch_rm_variant<NV, false, true, false>(c, k, d_over, d_under, early_out, ho); break;
+    case 3: launch_rm_variant<NV, false, true, true>(c, k, d_over, d_under, early_out, ho); break;
+    case 4: launch_rm_variant<NV, true, false, false>(c, k, d_over, d_under, early_out, ho); break;
+    case 5: launch_rm_variant<NV, true, false, true>(c, k, d_over, d_under, early_out, ho); break;
+    case 6: launch_rm_variant<NV, true, true, false>(c, k, d_over, d_under, early_out, ho); break;
+    default: launch_rm_variant<NV, true, true, true>(c, k, d_over, d_under, early_out, ho); break;
     }
 }
 
 }  // namespace
 
-int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
+int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, const RmHandoff* handoff)
 {
+    const RmHandoff ho = (handoff && d_under) ? *handoff : RmHandoff{};          // slab (partial-image) kernels only
     const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) ? 0 : 1;
     VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
     const int nocc = c->h_meta.occupied;
@@ -782,9 +803,9 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under)
     }
     VP_HIP(hipEventRecord(c->ev[2][0], c->stream));
     switch (k.nv) {
-    case 16: launch_rm_nv<16>(c, k, d_over, d_under, early_out); break;
-    case 32: launch_rm_nv<32>(c, k, d_over, d_under, early_out); break;
-    case 64: launch_rm_nv<64>(c, k, d_over, d_under, early_out); break;
+    case 16: launch_rm_nv<16>(c, k, d_over, d_under, early_out, ho); break;
+    case 32: launch_rm_nv<32>(c, k, d_over, d_under, early_out, ho); break;
+    case 64: launch_rm_nv<64>(c, k, d_over, d_under, early_out, ho); break;
     default: return vp_fail(c, VP_ERR_UNSUPPORTED, "num_voxels %d not built (16, 32, 64)", k.nv);
     }
     VP_HIP(hipGetLastError());

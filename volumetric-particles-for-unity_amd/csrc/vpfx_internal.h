@@ -15,8 +15,8 @@
 #define VPFX_CFG_NO_LDS_CUBEMAP 1
 // vp_config.reserved[1]: 1 keeps RGBA16F bricks when the ambient colour is grey (A/B against the luminance|density format)
 #define VPFX_CFG_NO_GREY_BRICKS 1
-// vp_config.reserved[2]: test hook -- the chained fill awaits tags nobody writes and gives up after a few polls (watchdog error path)
-#define VPFX_CFG_TEST_CHAIN_TIMEOUT 1
+// Test hook of the chained fill's watchdog: with the ENVIRONMENT variable VPFX_TEST_CHAIN_TIMEOUT=1 set when vp_create runs, the units await
+// tags nobody writes and give up after a few polls (error path).  Not reachable through the ABI structs.
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel-constant PODs (passed by value as kernel arguments -> SGPRs / kernarg segment)
@@ -71,6 +71,20 @@ struct RmConsts {
     float alpha_cutoff;           // early-out once (1 - dst.a) <= cutoff in the UNDER phase (0 = exact only)
 };
 
+// Cross-slab saturation hand-off of the ray-march (slab kernels only; raymarch.hip).  The reference's single render target sees every metavoxel (VPR.cs:652-711), so one
+// GPU stops a ray as soon as it is saturated; a slab on its own only knows its own metavoxels.  t_in = n maps [n][H][W] of the transmittance
+// (1 - alpha) of slabs that are composited IN FRONT of this one (received from the other GPUs); their product bounds what this slab can
+// still contribute, and a ray stops once (1 - dst.a) * prod(t_in) <= 2^-25 -- with no map that is exactly the single-GPU rule
+// 1 - dst.a == 0 (1 - a is a multiple of 2^-24 near a = 1), with maps it skips contributions of at most 3e-8.  t_out0 / t_out1 = this slab's
+// own transmittance for the slabs behind it: 1 - alpha(phase-A image) and (1 - alpha(A)) (1 - alpha(B)) (equal unless the slab straddles
+// zBoundary: phase-A slabs behind it are only hidden by its phase-A part).  zsamples[zz] += samples executed in light-axis slice zz (the work
+// profile the slab cut is balanced with).  All pointers nullable.
+struct RmHandoff {
+    const float* t_in; int n_in; size_t plane;
+    float* t_out0; float* t_out1;
+    unsigned* zsamples;
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Device-side buffers and context
 // ---------------------------------------------------------------------------------------------------
@@ -81,8 +95,12 @@ struct DevMeta {                  // small device-resident result block, copied 
     int unsorted_lists;           // MVs whose list was too long for the in-LDS rank sort
 };
 
+struct vp_multi;                  // multi.cpp: the fan-out (slab contexts, worker threads, RCCL communicator)
+
 struct vp_ctx {
     vp_config cfg{};
+    vp_multi* multi = nullptr;    // non-null: a fan-out context (its slabs live in child contexts); every entry point forwards
+    bool test_chain_timeout = false;
     int device = 0;
     hipStream_t stream = nullptr;
     GridConsts g{};
@@ -118,7 +136,7 @@ struct vp_ctx {
     DevMeta h_meta{};
 
     // fill
-    uint2* d_bricks = nullptr;    // [brick_cap][nv^3] RGBA16F (or, bricks_grey: the first half of it as [.][nv^3] luminance|density fp16 pairs)
+    uint2* d_bricks = nullptr;    // [brick_cap][nv^3] x 8 B: RGBA16F texels, or (bricks_grey) z-pair entries (luminance|density)(z), (luminance|density)(z + 1)
     bool bricks_grey = false;     // format of the bricks as last filled
     size_t brick_cap = 0;
     float2* d_dens_ao = nullptr;  // split-fill scratch [brick_cap][nv^3]
@@ -157,6 +175,7 @@ struct vp_ctx {
     float* d_image = nullptr;     // [H][W][4]
     float* d_scene_depth = nullptr;
     unsigned long long* d_samples = nullptr;
+    unsigned* d_zsamples = nullptr; // [Nz] samples executed per light-axis slice by the last slab ray-march (RmHandoff::zsamples)
     int* d_brick_hit = nullptr;   // [brick_hit_cap] set to 1 by the ray-march when a brick contributes a sample
     size_t brick_hit_cap = 0;
     long long last_samples = 0;
@@ -195,6 +214,10 @@ inline int rm_super_tiles_x(int W) { return (((W + 15) / 16) + (1 << VPFX_RM_LX)
 inline int rm_super_tiles_y(int H) { return (((H + 15) / 16) + (1 << VPFX_RM_LY) - 1) >> VPFX_RM_LY; }
 inline int rm_num_super_tiles(int W, int H) { return rm_super_tiles_x(W) * rm_super_tiles_y(H); }
 void   hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank);  //           VPR.cs:613-632
+// slab cut + compositing order of the slabs (host only)
+void   hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms, int rm_groups, int* cuts /* [world + 1] */);
+int    hl_blend_plan(int world, const int* cuts, int zb, int* chain, int* plan_rank, int* plan_which, int* plan_kind, int* straddler);
+void   hl_chain_groups(int world, int rm_groups, int* group_of_pos /* [world]: group of chain position p */);
 void   hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k);
 
 // bin.hip
@@ -210,10 +233,34 @@ int  launch_fill_one(vp_ctx* c, int xx, int yy, int zz);
 int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v);                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
 // raymarch.hip
-int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under);
+int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, const RmHandoff* handoff = nullptr);
 int  launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_over, int order_index, float* d_img);  // RenderMetavoxel VPR.cs:766
 int    launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out, size_t npix);
 int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);
+// api.cpp: the single-device entry points the fan-out calls on its slab contexts
+int  vp_create_single(const vp_config* cfg, vp_ctx** out);
+void vp_destroy_single(vp_ctx* c);
+int  api_stream_sync(vp_ctx* c);
+int  api_upload_particles(vp_ctx* c, const void* particles, int32_t count, const vp_particle_layout* lay, const float* psys_l2w, bool sync);
+int  api_stage_fill_inputs(vp_ctx* c, const vp_fill_params* p);
+int  api_ensure_bricks(vp_ctx* c, bool need_scratch);
+int  api_stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k);
+int  api_set_slab(vp_ctx* c, int z0, int z1);
+// multi.cpp
+int  multi_create(const vp_config* cfg, vp_ctx** out);
+void multi_destroy(vp_ctx* c);
+int  multi_set_frame(vp_ctx* c, const float* l2w, const float* gc);
+int  multi_upload_particles(vp_ctx* c, const void* particles, int32_t count, const vp_particle_layout* lay, const float* psys_l2w);
+int  multi_bin_resident(vp_ctx* c);
+int  multi_fill(vp_ctx* c, const vp_fill_params* p);
+int  multi_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, float* host_out, void* d_out);
+int  multi_sync(vp_ctx* c);
+int  multi_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n);
+int  multi_get_stats(vp_ctx* c, vp_stats* st);
+int  multi_last_kernel_ms(vp_ctx* c, int stage, float* ms);
+int  multi_read_bincounts(vp_ctx* c, int32_t* counts);
+int  multi_read_lightmap(vp_ctx* c, float* out);
+vp_ctx* multi_owner_of_slice(vp_ctx* c, int zz);       // local child owning light-axis slice zz, or nullptr
 // occluders.hip
 int  launch_light_depth(vp_ctx* c, float nearz, float farz, float cam_dist, float* d_out);
 int  launch_scene_depth(vp_ctx* c, const vp_camera* cam, float* d_out);

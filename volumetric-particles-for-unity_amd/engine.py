@@ -243,6 +243,33 @@ class Engine:
         self._ck(self.L.vp_z_boundary(self.h, C.byref(cam), C.byref(zb)), "vp_z_boundary")
         return zb.value
 
+    # -- multi-GPU ------------------------------------------------------------------------------------
+    def raymarch_partial_handoff_device(self, cam, rp, d_over: int, d_under: int, d_t_in: int = 0, n_in: int = 0, d_t_out0: int = 0,
+                                        d_t_out1: int = 0) -> int:
+        mask = C.c_int32(0)
+        self._ck(self.L.vp_raymarch_partial_handoff_device(self.h, C.byref(cam), C.byref(rp), C.c_void_p(d_over), C.c_void_p(d_under), C.byref(mask),
+                                                           C.c_void_p(d_t_in), int(n_in), C.c_void_p(d_t_out0), C.c_void_p(d_t_out1)),
+                 "vp_raymarch_partial_handoff_device")
+        return mask.value
+
+    def zsamples(self):
+        out = np.zeros(self.N[2], dtype=np.int64)
+        self._ck(self.L.vp_read_zsamples(self.h, _vp(out)), "vp_read_zsamples")
+        return out
+
+    def rebalance(self):
+        """Fan-out contexts: re-cut the slabs at the next bin from the measured work histograms."""
+        self._ck(self.L.vp_rebalance(self.h), "vp_rebalance")
+
+    def multi_info(self):
+        mi = abi.vp_multi_info()
+        self._ck(self.L.vp_get_multi_info(self.h, C.byref(mi)), "vp_get_multi_info")
+        w = mi.world_size
+        return dict(world_size=w, num_local=mi.num_local, first_rank=mi.first_rank, rccl_ranks=mi.rccl_ranks,
+                    exchange="all_gather" if mi.exchange else "tiles", rm_groups=mi.rm_groups, slab_cuts=list(mi.slab_cuts[: w + 1]),
+                    chain=list(mi.chain[:w]), group_of=list(mi.group_of[:w]), samples=list(mi.samples[:w]),
+                    stage_ms=[list(mi.stage_ms[r]) for r in range(w)], exchange_ms=list(mi.exchange_ms[:3]))
+
     # -- stats ---------------------------------------------------------------------------------------
     def stats(self):
         st = abi.vp_stats()
@@ -253,6 +280,39 @@ class Engine:
         ms = C.c_float(0)
         self._ck(self.L.vp_last_kernel_ms(self.h, stage, C.byref(ms)), "vp_last_kernel_ms")
         return ms.value
+
+
+def rccl_unique_id() -> bytes:
+    """128 bytes naming a new RCCL communicator (rank 0 of a multi-process job calls this and hands them to every process)."""
+    buf = (C.c_uint8 * 128)()
+    rc = lib().vp_rccl_unique_id(buf)
+    if rc:
+        raise VpfxError("vp_rccl_unique_id", rc, lib().vp_last_error(None).decode())
+    return bytes(buf)
+
+
+def plan_slabs(nz: int, world: int, fill_ms=None, rm_ms=None, rm_groups: int = 1):
+    """The library's slab cut (host only; no GPU needed): [(z0, z1)] per rank."""
+    f = None if fill_ms is None else (C.c_double * nz)(*[float(x) for x in fill_ms])
+    r = None if rm_ms is None else (C.c_double * nz)(*[float(x) for x in rm_ms])
+    cuts = (C.c_int32 * (world + 1))()
+    rc = lib().vp_plan_slabs(int(nz), int(world), f, r, int(rm_groups), cuts)
+    if rc:
+        raise VpfxError("vp_plan_slabs", rc, lib().vp_last_error(None).decode())
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+def blend_plan(bounds, z_boundary: int):
+    """The library's compositing order of the slabs: (chain, plan, straddler); plan = [(rank, which, kind)], which 0 = the slab's first
+    image, 1 = the straddler's phase-B image; kind 0 = OVER, 1 = UNDER; chain = ranks front to back."""
+    world = len(bounds)
+    cuts = (C.c_int32 * (world + 1))(*([b[0] for b in bounds] + [bounds[-1][1]]))
+    chain, pr, pw, pk = ((C.c_int32 * (world + 1))() for _ in range(4))
+    n, strad = C.c_int32(0), C.c_int32(-1)
+    rc = lib().vp_blend_plan(world, cuts, int(z_boundary), chain, pr, pw, pk, C.byref(n), C.byref(strad))
+    if rc:
+        raise VpfxError("vp_blend_plan", rc, lib().vp_last_error(None).decode())
+    return list(chain[:world]), [(pr[i], pw[i], pk[i]) for i in range(n.value)], (None if strad.value < 0 else strad.value)
 
 
 def _copy_cfg(cfg):

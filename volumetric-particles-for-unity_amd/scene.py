@@ -139,8 +139,20 @@ class Scene:
     far: float = 1000.0
 
     # ---- ctypes views (keep the numpy arrays alive on self) -------------------------------------
-    def config(self, device: int = -1, slab=(0, 0)) -> abi.vp_config:
+    def config(self, device: int = -1, slab=(0, 0), devices=None, world_size: int = 0, first_rank: int = 0, multi_flags: int = 0,
+               rm_groups: int = 0, rccl_unique_id: bytes | None = None) -> abi.vp_config:
+        """devices = [ordinals]: a fan-out context (the library cuts the grid into len(devices) slabs, one per GPU; world_size / first_rank /
+        rccl_unique_id: this process's share of a multi-process job)."""
         cfg = abi.vp_config()
+        if devices is not None:
+            cfg.num_devices = len(devices)
+            for i, d in enumerate(devices):
+                cfg.devices[i] = d
+        cfg.world_size, cfg.first_rank, cfg.multi_flags, cfg.rm_groups = world_size, first_rank, multi_flags, rm_groups
+        if rccl_unique_id is not None:
+            assert len(rccl_unique_id) == 128
+            for i, b in enumerate(rccl_unique_id):
+                cfg.rccl_unique_id[i] = b
         cfg.num_mv[0], cfg.num_mv[1], cfg.num_mv[2] = self.N
         cfg.num_voxels = self.nv
         cfg.num_border = self.border
