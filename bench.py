@@ -6,8 +6,13 @@ One "step" = one full pass of the hot path over one batch of synthetic input tha
 
 Workload at N = 1: BASELINE.json configs[2], the configuration its metric is quoted on:
     32x32x32 metavoxels x 32^3 voxels, 100k particles, 1920x1080 (synthetic scene of SURVEY.md 8(d)).
-N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME grid split into light-axis slabs
-(BASELINE.json configs[3]) -> strong scaling; two all-gathers per step (slab transmittance, partial images).
+N > 1: the SAME grid cut into light-axis slabs (BASELINE.json configs[3]) -> strong scaling.  The multi-GPU fan-out lives INSIDE libvpfx
+(csrc/multi.cpp: device list in vp_config, one worker thread + HIP stream + RCCL rank per GPU); this script only makes the same
+vp_bin_resident / vp_fill / vp_raymarch calls as at N = 1.  Two launch styles, one code path in the library:
+    python bench.py --gpus N                          one process drives the N GPUs (ncclCommInitAll) -- what the C# / C host does
+    python -m torch.distributed.run ... bench.py --gpus N   one process per GPU (ncclCommInitRank; the unique id travels over a gloo
+                                                      group, which also carries the barrier and the max-over-ranks of the timing)
+torch.distributed never touches RCCL here: every data-path collective is issued by the library.
 
 Prints ONE JSON line on rank 0.  `value` = (voxels filled + samples ray-marched) per second over the whole job,
 in millions; the two halves are also reported separately.
@@ -28,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 
 load_package()
-from vpfx_amd import engine as E, parallel as PAR, scene as S  # noqa: E402
+from vpfx_amd import abi, engine as E, scene as S  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -38,26 +43,27 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "Mvoxels/s filled + Msamples/s raymarched, 32\u00b3\u00d732\u00b3 grid @1080p"
+        return "Mvoxels/s filled + Msamples/s raymarched, 32³×32³ grid @1080p"
 
 
 def kernel_sources_sha():
-    """Fingerprint of the kernel sources: profiles/traffic_<cfg>.json records the one it was measured on, and bench.py only
-    reports that PMC measurement as `roofline.traffic` while it still matches (a stale number is worse than null)."""
+    """Fingerprint of the kernel sources: profiles/traffic_<cfg>.json and profiles/limiters_<cfg>.json record the one they were measured on,
+    and bench.py only reports those PMC measurements while it still matches (a stale number is worse than null)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cpp", ".h")):
+        if f in ("fill.hip", "raymarch.hip", "bin.hip", "vpfx_internal.h"):      # the kernels (host-side files do not change a counter)
             h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def cpu_baseline(sc, threads=0):
     """Time the CPU oracle (a port of the reference's algorithm; the reference itself is C# + HLSL and cannot run
-    here) on the GPU box's host cores.  Reported, not shipped: this is the only place bench.py touches oracle/."""
+    here) on the GPU box's host cores, compiled -march=native on that box.  Reported, not shipped: this is the only place bench.py
+    touches oracle/."""
     from oracle import oracle as O
-    o = O.Oracle(sc.config(), threads=threads)
+    o = O.Oracle(sc.config(), threads=threads, native=True)
     o.set_frame(sc.light_to_world, sc.grid_center)
     t0 = time.perf_counter()
     o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
@@ -69,8 +75,8 @@ def cpu_baseline(sc, threads=0):
     st = o.stats()
     units = st["voxels_filled"] + st["samples"]
     out = {
-        "value": units / (t3 - t0) / 1e6, "unit": "M(voxels+samples)/s", "cores": threads or O.Oracle.max_threads(),
-        "kind": "port",
+        "value": units / (t3 - t0) / 1e6, "unit": "M(voxels+samples)/s", "cores": threads or o.L.vpo_max_threads(),
+        "kind": "port", "build": "gcc -O3 -march=native -fopenmp, built on this box",
         "sample": f"one full step of {sc.name} (bin {t1 - t0:.3f}s, fill {t2 - t1:.3f}s, raymarch {t3 - t2:.3f}s)",
         "fill_mvoxels_per_s": st["voxels_filled"] / (t2 - t1) / 1e6,
         "raymarch_msamples_per_s": st["samples"] / (t3 - t2) / 1e6,
@@ -80,7 +86,7 @@ def cpu_baseline(sc, threads=0):
     # single-thread leg: ONE light-axis slice of the same workload (the middle one) on one thread, extrapolated
     # to the whole step with the per-unit rates (a full single-thread step would take minutes)
     zmid = sc.N[2] // 2
-    o1 = O.Oracle(sc.config(slab=(zmid, zmid + 1)), threads=1)
+    o1 = O.Oracle(sc.config(slab=(zmid, zmid + 1)), threads=1, native=True)
     o1.set_frame(sc.light_to_world, sc.grid_center)
     o1.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     s0 = time.perf_counter()
@@ -105,7 +111,7 @@ def cpu_baseline(sc, threads=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 1 s of timed region at ~5 ms per step)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 1 s of timed region at ~4 ms per step)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="scene name from vpfx_amd.scene.CONFIGS (default: the metric's config)")
     ap.add_argument("--cubemap", default="r8", choices=["r8", "f32"],
@@ -116,58 +122,73 @@ def main():
                     help="override the scene's _DisplacementScale (default 0.7, scene:9016); 1.0 = the slider's maximum (smoothstep jump at net displacement 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
-    ap.add_argument("--share-gpu", action="store_true", help="functional test only: all ranks on cuda:0")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional test only: all N slabs on cuda:0 through the library's peer-copy test hook (no RCCL, nothing to scale)")
     ap.add_argument("--exchange", default="tiles", choices=["tiles", "all_gather"],
-                    help="N > 1 image exchange: all-to-all of screen pieces + sharded blend (default) or one all-gather of whole partial images")
-    ap.add_argument("--uniform-slabs", action="store_true", help="equal-thickness slabs instead of pair-count balanced ones")
+                    help="N > 1 image exchange: all-to-all of screen pieces + sharded blend + gather (default) or one all-gather of whole partial images")
+    ap.add_argument("--rm-groups", type=int, default=0, help="N > 1: groups of the ray-march saturation hand-off (1 = none, N = serial chain, 0 = library default)")
+    ap.add_argument("--uniform-slabs", action="store_true", help="equal-thickness slabs instead of the work-balanced cut")
     ap.add_argument("--no-reference-frame", action="store_true", help="N > 1: do not render the 1-GPU frame on rank 0 for the shard check")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if args.share_gpu:
-        local_rank = 0
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    N = args.gpus
+    multi_process = env_world > 1
+    if multi_process and env_world != N:
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={env_world}")
+    rank = int(os.environ.get("RANK", "0")) if multi_process else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if multi_process else 0
+    if args.share_gpu and multi_process:
+        raise SystemExit("--share-gpu is the single-process test hook (python bench.py --gpus N --share-gpu)")
+    ngpu = torch.cuda.device_count()
+    if N > 1 and not multi_process and not args.share_gpu and ngpu < N:
+        raise SystemExit(f"--gpus {N} but only {ngpu} GPU(s) visible (functional run on one GPU: add --share-gpu)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+    if multi_process:
+        dist.init_process_group("gloo")          # control plane only: unique id, barrier, timing reduction.  RCCL belongs to the library.
 
     sc = S.make_scene(args.config, cubemap=args.cubemap)
     if args.displacement_scale is not None:
         sc.displacement_scale = float(args.displacement_scale)
-    weights, fill_w, rm_w, whole_occupied = None, None, None, None
-    if world > 1:
-        # every rank computes the same (particle, MV)-pair histogram along the light axis (balanced slabs) and the
-        # whole-grid occupancy (sizes the optional 1-GPU reference frame below); binning allocates no bricks
+
+    flags = (abi.VP_MULTI_EXCHANGE_ALL_GATHER if args.exchange == "all_gather" else 0) | (abi.VP_MULTI_UNIFORM_SLABS if args.uniform_slabs else 0)
+    launch = "single GPU"
+    if N == 1:
+        cfg = sc.config(device=local_rank)
+    elif multi_process:
+        uid = [E.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        cfg = sc.config(devices=[local_rank], world_size=N, first_rank=rank, multi_flags=flags, rm_groups=args.rm_groups, rccl_unique_id=uid[0])
+        launch = f"one process per GPU ({N} ranks, torch.distributed.run), RCCL inside libvpfx (ncclCommInitRank)"
+    elif args.share_gpu:
+        cfg = sc.config(devices=[0] * N, multi_flags=flags | abi.VP_MULTI_PEER_COPY, rm_groups=args.rm_groups)
+        launch = f"one process, {N} slabs on ONE GPU through the peer-copy test hook (functional run: no RCCL, no scaling)"
+    else:
+        cfg = sc.config(devices=list(range(N)), multi_flags=flags, rm_groups=args.rm_groups)
+        launch = f"one process drives {N} GPUs, RCCL inside libvpfx (ncclCommInitAll)"
+    if args.no_lds_cubemap:
+        cfg.reserved[0] = 1            # VPFX_CFG_NO_LDS_CUBEMAP
+    if args.no_grey:
+        cfg.reserved[1] = 1            # VPFX_CFG_NO_GREY_BRICKS
+
+    # strong scaling: the unit of work is the SINGLE-GPU job (its voxels and its executed samples).  Sharded runs may execute
+    # more lattice samples in total (slabs of one hand-off group do not see each other's opacity), which must not inflate `value`.
+    ref_units, ref_image, ref_skipped = None, None, None
+    if N > 1 and rank == 0:
+        # The 1-GPU reference frame is rendered on rank 0's GPU only if the whole grid's brick pool fits NEXT TO the slab engine(s)
+        # that GPU also hosts: at config 5 it is ~190 GB and must not be attempted.
         probe = E.Engine(sc.config(device=local_rank))
         probe.set_frame(sc.light_to_world, sc.grid_center)
         probe.bin(sc.particles, sc.layout, sc.psys_local_to_world)
-        counts = probe.bin_counts()
-        mvpos = probe.mv_positions()
         whole_occupied = probe.stats()["occupied_mv"]
         probe.close()
-        if not args.uniform_slabs:
-            # estimated ms per light-axis slice: fill (~ pairs) + this camera's ray-march (~ screen footprint of the occupied MVs)
-            weights, fill_w, rm_w = PAR.slice_costs(counts, mvpos, sc.cam_pos, sc.mv_scale, sc.height, np.radians(sc.fov_y_deg), sc.steps)
-    bounds = PAR.choose_slabs(sc.N[2], world, fill_w, rm_w) if weights is not None else PAR.slab_bounds(sc.N[2], world, None)
-    # strong scaling: the unit of work is the SINGLE-GPU job (its voxels and its executed samples).  Sharded runs execute
-    # more lattice samples in total (the saturation early-out only sees one slab), which must not inflate `value`.
-    ref_units, ref_image, ref_skipped = None, None, None
-    if world > 1 and rank == 0:
-        # The 1-GPU reference frame is rendered on rank 0 only if the whole grid's brick pool fits NEXT TO this rank's slab
-        # engine (bricks + 16 B/voxel split-fill scratch): at config 5 it is ~190 GB and must not be attempted.
         brick = 8 * sc.nv ** 3
+        share = N if args.share_gpu else 1
         need_ref = whole_occupied * brick * 1.125 + 2e9
-        need_slab = 3.0 * (whole_occupied / world) * 1.5 * brick * 1.125 + 2e9      # bricks + 2x scratch, 1.5x for an uneven slab
+        need_slab = 3.0 * (whole_occupied / N) * share * 1.5 * brick * 1.125 + 2e9      # bricks + 2x scratch, 1.5x for an uneven slab
         free, _ = torch.cuda.mem_get_info()
         if need_ref + need_slab > 0.9 * free or args.no_reference_frame:
             ref_skipped = (f"1-GPU reference frame skipped: whole-grid brick pool {need_ref / 1e9:.0f} GB + slab engine "
@@ -185,53 +206,63 @@ def main():
             ref_units = (st1["voxels_filled"], st1["samples"])
             one.close()
             torch.cuda.empty_cache()
-    cfg = sc.config(device=local_rank, slab=bounds[rank] if world > 1 else (0, 0))
-    if args.no_lds_cubemap:
-        cfg.reserved[0] = 1            # VPFX_CFG_NO_LDS_CUBEMAP
-    if args.no_grey:
-        cfg.reserved[1] = 1            # VPFX_CFG_NO_GREY_BRICKS
+
     eng = E.Engine(cfg)
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
-    pipe = PAR.SlabPipeline(PAR.HipSlabEngine(eng, device), bounds, rank, world, exchange=args.exchange)
     fp_first, fp = sc.fill_params(), sc.fill_params()
     fp.cubemap = None                                                           # cubemap stays resident after the first fill
     cam, rp = sc.camera(), sc.raymarch_params()
+    image = torch.empty((sc.height, sc.width, 4), device=device)                # particlesRT on the display GPU (rank 0)
 
     def step(first=False):
-        pipe.fill(fp_first if first else fp)
-        return pipe.render(cam, rp)
+        eng.bin_resident()
+        eng.fill(fp_first if first else fp)
+        eng.raymarch_device(cam, rp, image.data_ptr())
+
+    sync_devices = list(range(N)) if (N > 1 and not multi_process and not args.share_gpu) else [local_rank]
 
     def barrier():
-        if world > 1:
+        eng.sync()
+        if multi_process:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in sync_devices:
+            torch.cuda.synchronize(d)
 
     step(first=True)
-    for _ in range(max(args.warmup - 1, 0)):
+    # N > 1: re-cut the slabs twice from the measured work (pairs per slice, samples executed per slice, kernel times), then keep the cut:
+    # vp_rebalance makes the NEXT ray-march record its per-slice samples and the bin after that re-cut, hence the extra step at the end
+    for i in range(max(args.warmup - 1, 3 if N > 1 else 0)):
+        if N > 1 and i < 2 and not args.uniform_slabs:
+            eng.rebalance()
         step()
     barrier()
     k_fill, k_rm, k_bin, k_fin = [], [], [], []
     t0 = time.perf_counter()
-    image = None
     for _ in range(args.steps):
-        image = step()
-        # HIP-event durations of the dominant kernels, recorded on the stream they were launched on
+        step()
+        # HIP-event durations of the dominant kernels, recorded on the stream they were launched on (N > 1: the slowest local rank)
         k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))
-        if world > 1:
+        if N > 1:
             k_fin.append(eng.last_kernel_ms(3))
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
     st = eng.stats()
-    counts = torch.tensor([st["voxels_filled"], st["samples"], st["occupied_mv"], st["pairs"], st["bricks_sampled"]],
-                          dtype=torch.float64, device=device)
+    info = eng.multi_info()
+    t = torch.tensor([dt], dtype=torch.float64)
+    counts = torch.tensor([st["voxels_filled"], st["samples"], st["occupied_mv"], st["pairs"], st["bricks_sampled"]], dtype=torch.float64)
     stage_max = torch.tensor([float(np.mean(k_bin)), float(np.mean(k_fill)), float(np.mean(k_rm)), float(np.mean(k_fin)) if k_fin else 0.0],
-                             dtype=torch.float64, device=device)
-    if world > 1:
+                             dtype=torch.float64)
+    per_rank = torch.zeros((max(N, 1), 5), dtype=torch.float64)                 # samples + the four stage kernel times of every rank
+    if N > 1:
+        for r in range(info["first_rank"], info["first_rank"] + info["num_local"]):
+            per_rank[r, 0] = info["samples"][r]
+            per_rank[r, 1:] = torch.tensor(info["stage_ms"][r], dtype=torch.float64)
+    if multi_process:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(stage_max, op=dist.ReduceOp.MAX)          # slowest rank per stage (kernel time, HIP events)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
     dt = float(t.item())
     voxels, samples, occupied, pairs, bricks_sampled = [float(x) for x in counts.tolist()]
 
@@ -239,99 +270,109 @@ def main():
         ms_step = dt / args.steps * 1e3
         nv = sc.nv
         fill_ms, rm_ms, bin_ms = float(np.mean(k_fill)), float(np.mean(k_rm)), float(np.mean(k_bin))
-        # algorithmic bytes; rank-0 slab for N > 1
-        # bricks are counted at the bytes per voxel the context actually stores (8 in both formats = SURVEY's figure)
+        # algorithmic bytes; bricks are counted at the bytes per voxel the context actually stores (8 in both formats)
         lds_path = args.cubemap == "r8" and not args.no_lds_cubemap
         bpv = st.get("brick_bytes_per_voxel", 8)
-        fill_bytes = st["occupied_mv"] * (bpv * nv ** 3 + 8 * nv ** 2) + 84 * st["pairs"]
-        rm_bytes = st["bricks_sampled"] * bpv * nv ** 3 + 16 * sc.width * sc.height
+        fill_bytes = occupied * (bpv * nv ** 3 + 8 * nv ** 2) + 84 * pairs
+        rm_bytes = bricks_sampled * bpv * nv ** 3 + 16 * sc.width * sc.height
+        smax = [float(x) for x in stage_max.tolist()]
+        fill_t = (smax[1] + smax[3]) * 1e-3                         # fill = local pass + finish pass on the slowest rank for N > 1
         roofs = {
-            "fill": {"bound": "hbm", "kernel": "k_fill_lds" if lds_path else "k_fill", "achieved": fill_bytes / (fill_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "bytes_per_launch": fill_bytes, "avg_ms": fill_ms, "brick_bytes_per_voxel": bpv},
-            "raymarch": {"bound": "hbm", "kernel": "k_raymarch", "achieved": rm_bytes / (rm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "bytes_per_launch": rm_bytes, "avg_ms": rm_ms, "brick_bytes_per_voxel": bpv,
-                         "requested_GBps_per_sample_footprint": st["samples"] * 8 * bpv / (rm_ms * 1e-3) / 1e9},
+            "fill": {"bound": "hbm", "kernel": "k_fill_lds" if lds_path else "k_fill", "achieved": fill_bytes / fill_t / 1e9 / N,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_launch": fill_bytes / N, "avg_ms": fill_t * 1e3,
+                     "brick_bytes_per_voxel": bpv},
+            "raymarch": {"bound": "hbm", "kernel": "k_raymarch", "achieved": rm_bytes / (smax[2] * 1e-3) / 1e9 / N, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "bytes_per_launch": rm_bytes / N, "avg_ms": smax[2], "brick_bytes_per_voxel": bpv,
+                         "requested_GBps_per_sample_footprint": samples * 8 * bpv / (smax[2] * 1e-3) / 1e9 / N},
         }
-        # HBM traffic per launch measured with rocprofv3 PMC passes (scripts/gpu_prof2.sh -> profiles/*traffic*.json);
-        # bench.py cannot collect PMC counters itself, so the committed measurement of this same command is reported.
-        traffic, tnote = {}, None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{args.cubemap}.json")
-        if world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))
-            if traffic.get("kernel_sources_sha") != kernel_sources_sha() or args.no_lds_cubemap or args.no_grey:
-                tnote = (f"profiles/{os.path.basename(tpath)} was measured on other kernel sources "
-                         f"({traffic.get('kernel_sources_sha')} != {kernel_sources_sha()}) or another code path (A/B switch): not reported")
-                traffic = {}
+        # HBM traffic per launch and the issue-side counters, measured with rocprofv3 PMC passes of this same command
+        # (scripts/gpu_prof_r3.sh -> profiles/traffic_<cfg>_<cubemap>.json, limiters_<cfg>_<cubemap>.json); bench.py cannot collect PMC
+        # counters itself, so the committed measurement is reported -- only while the kernel sources still have the fingerprint it was
+        # taken on and no A/B switch changes the code path; otherwise null.
+        sha = kernel_sources_sha()
+        ab = args.no_lds_cubemap or args.no_grey or args.displacement_scale is not None
+
+        def measured(kind):
+            path = os.path.join(ROOT, "profiles", f"{kind}_{args.config}_{args.cubemap}.json")
+            if N != 1 or not os.path.exists(path):
+                return {}, None
+            d = json.load(open(path))
+            if d.get("kernel_sources_sha") != sha or ab:
+                return {}, (f"profiles/{os.path.basename(path)} was measured on other kernel sources ({d.get('kernel_sources_sha')} != {sha}) "
+                            f"or another code path (A/B switch): not reported")
+            return d, None
+        traffic, tnote = measured("traffic")
+        limiters, lnote = measured("limiters")
         for name, r in roofs.items():
             r["frac"] = r["achieved"] / r["peak"]
-            t = traffic.get(r["kernel"])
-            r["traffic"] = t["traffic_bytes"] if t else None
-            if t:
-                r["traffic_source"] = (f"profiles/{os.path.basename(tpath)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes of this "
-                                       f"command on these kernel sources, sha {traffic['kernel_sources_sha']})")
+            tr = traffic.get(r["kernel"])
+            r["traffic"] = tr["traffic_bytes"] if tr else None
+            if tr:
+                r["traffic_source"] = (f"profiles/traffic_{args.config}_{args.cubemap}.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes of "
+                                       f"this command on these kernel sources, sha {sha})")
             elif tnote:
                 r["traffic_note"] = tnote
-        # what actually limits the two kernels (rocprofv3 PMC passes of this command, profiles/ + DESIGN.md 3.4): not HBM
-        roofs["fill"]["limiter"] = (("VALU issue: ~2.0 G wave-level VALU per launch at ~4 cycles each = the whole kernel time (SQ_ACTIVE_INST_VALU x 4 / "
-                                     "SIMD-cycles ~ 1.0); the cube map is LDS-resident (LDS pipe ~60 % busy, 3/4 of it bank conflicts); HBM at ~0.9 TB/s")
-                                    if lds_path else
-                                    ("the CU's single L1/TA path: one divergent wave-wide footprint gather per covered slice (~65 cycles per "
-                                     "wave-slice per CU against ~38 of VALU); HBM at ~0.65 TB/s"))
-        roofs["raymarch"]["limiter"] = (("VALU issue: ~51 VALU per wave-sample, SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles ~ 0.78, 59 % of the lanes active; two 16-B "
-                                         "footprint loads per sample (grey z-pair bricks), L1 at ~60 % of its access rate; HBM at ~2.5 TB/s")
-                                        if st.get("brick_format", 0) == 1 else
-                                        ("L1 (TCP): four 16-B footprint loads per sample, one lane quad per L1 cycle at best: TCP busy 96 %, ~26.5 L1 "
-                                         "cycles per wave-load (profiles/r02_l1_gather_probe.txt); VALU hides underneath; HBM at ~1.6 TB/s"))
-        smax = [float(x) for x in stage_max.tolist()]
-        # whole-job algorithmic bytes (all ranks): bricks + light map + pair records; bricks sampled + the image
-        fill_bytes_job = occupied * (bpv * nv ** 3 + 8 * nv ** 2) + 84 * pairs
-        rm_bytes_job = bricks_sampled * bpv * nv ** 3 + 16 * sc.width * sc.height
-        dom = "fill" if fill_ms >= rm_ms else "raymarch"
+            # what limits the kernel instead of HBM: counter-derived figures read from profiles/, or null (no prose that could go stale)
+            r["limiter"] = limiters.get(r["kernel"])
+            if lnote and not r["limiter"]:
+                r["limiter_note"] = lnote
+        dom = "fill" if fill_t * 1e3 >= smax[2] else "raymarch"
         executed = (voxels, samples)
         if ref_units is not None:
             voxels, samples = float(ref_units[0]), float(ref_units[1])
         # N > 1: the sharded frame against the single-GPU frame rendered on this rank before the timed region
-        shard_err = float((image - ref_image).abs().max().item()) if (ref_image is not None and image is not None) else None
+        shard_err = float((image - ref_image).abs().max().item()) if ref_image is not None else None
+        ex = info["exchange_ms"]
         out = {
             "metric": baseline_metric(),
             "value": (voxels + samples) / (dt / args.steps) / 1e6,
             "unit": "M(voxels+samples)/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 compute / f16 voxel storage", "data": "synthetic",
             "config": {"workload": f"{args.config}: {sc.N[0]}x{sc.N[1]}x{sc.N[2]} metavoxels x {nv}^3 voxels, "
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
                        "cubemap": ("R8 (8-bit like the reference's asset; LDS-resident in k_fill)" if args.cubemap == "r8" and not args.no_lds_cubemap
                                    else "R8 on the global f32 footprint table" if args.cubemap == "r8" else "f32 texels, global footprint table"),
+                       "displacement_scale": sc.displacement_scale,
                        "brick_storage": ("grey z-pair entries: (luminance|density)(z), (luminance|density)(z+1), 8 B/voxel (grey ambient: r = g = b bit for bit)"
                                          if st.get("brick_format", 0) == 1 else "RGBA16F, 8 B/voxel"),
-                       "parallelism": f"zslab{world}" + (f" ({args.exchange} exchange)" if world > 1 else ""), "slabs": bounds if world > 1 else None,
+                       "parallelism": f"zslab{N}" + (f" ({info['exchange']} exchange, {info['rm_groups']} hand-off group(s))" if N > 1 else ""),
+                       "launch": launch,
+                       "rccl_ranks": info["rccl_ranks"] if N > 1 else None,        # ncclCommCount of the library's communicator
+                       "slabs": [[a, b] for a, b in zip(info["slab_cuts"], info["slab_cuts"][1:])] if N > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),
-                       "work_unit": ("voxels + executed samples of the 1-GPU job (fixed for every N)" if (world == 1 or ref_units is not None)
+                       "work_unit": ("voxels + executed samples of the 1-GPU job (fixed for every N)" if (N == 1 or ref_units is not None)
                                      else "voxels + samples executed on all ranks (1-GPU reference job not run: see reference_frame_skipped)"),
                        "samples_executed_all_ranks": int(executed[1]),
                        "max_abs_rgba_diff_vs_1gpu_frame": shard_err, "reference_frame_skipped": ref_skipped},
             # absolute rates: per stage against that stage's kernel time on the slowest rank (fill = local + finish for N > 1),
             # and for the whole frame (everything incl. the exchanges)
-            "fill_mvoxels_per_s": voxels / ((smax[1] + smax[3]) * 1e-3) / 1e6,
+            "fill_mvoxels_per_s": voxels / fill_t / 1e6,
             "raymarch_msamples_per_s": samples / (smax[2] * 1e-3) / 1e6,
             "frame_mvoxels_per_s": voxels / (dt / args.steps) / 1e6,
             "frame_msamples_per_s": samples / (dt / args.steps) / 1e6,
-            "fill_frac_of_hbm_roofline": (fill_bytes_job / ((smax[1] + smax[3]) * 1e-3) / 1e9) / (HBM_PEAK_GBS * world),
-            "raymarch_frac_of_hbm_roofline": (rm_bytes_job / (smax[2] * 1e-3) / 1e9) / (HBM_PEAK_GBS * world),
+            "fill_frac_of_hbm_roofline": roofs["fill"]["frac"],
+            "raymarch_frac_of_hbm_roofline": roofs["raymarch"]["frac"],
             "stage_ms": {"bin": bin_ms, "fill_kernel": fill_ms, "raymarch_kernel": rm_ms,
                          "fill_finish_kernel": float(np.mean(k_fin)) if k_fin else None},
             "stage_ms_slowest_rank": {"bin": smax[0], "fill_kernel": smax[1], "raymarch_kernel": smax[2],
-                                      "fill_finish_kernel": smax[3] if world > 1 else None},
+                                      "fill_finish_kernel": smax[3] if N > 1 else None},
+            # N > 1: stream time of the exchanges on rank 0 (last step): tau all-gather, waiting for the saturation hand-off, image exchange + blend
+            "exchange_ms": {"tau_all_gather": ex[0], "handoff_wait": ex[1], "t_blend_image_exchange_and_blend": ex[2]} if N > 1 else None,
+            "per_rank": ({"samples": [int(x) for x in per_rank[:, 0].tolist()],
+                          "kernel_ms_bin_fill_raymarch_finish": [[round(float(v), 4) for v in row[1:]] for row in per_rank.tolist()],
+                          "handoff_chain_front_to_back": info["chain"], "handoff_group_of_rank": info["group_of"]} if N > 1 else None),
             "roofline": dict(roofs[dom], stage=dom),
             "roofline_all": roofs,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_threads)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    eng.close()
+    if multi_process:
         dist.destroy_process_group()
 
 

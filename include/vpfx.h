@@ -78,8 +78,9 @@ typedef struct vp_config {
     int32_t first_rank;       /* rank of devices[0] (ranks of one process are consecutive)                            */
     int32_t multi_flags;      /* VP_MULTI_* bits                                                                       */
     int32_t rm_groups;        /* saturation hand-off: the slabs, front to back, form this many groups; a group's slabs march
-                                 concurrently knowing the opacity of every earlier group.  1 = no hand-off, world_size = a fully
-                                 serial chain (fewest samples, longest latency), 0 = default (2 from 4 ranks on)     */
+                                 concurrently knowing the opacity of every earlier group.  0 / 1 = no hand-off (default: every slab
+                                 marches at once -- shortest frame, most samples), world_size = a fully serial chain (exactly the
+                                 single GPU's samples, longest frame: the groups run one after the other)             */
     uint8_t rccl_unique_id[128];
 } vp_config;
 
@@ -289,8 +290,10 @@ typedef struct vp_multi_info {
     float   exchange_ms[4];       /* rank-0-of-this-process stream time: tau all-gather, saturation hand-off, image exchange + blend, - */
 } vp_multi_info;
 int  vp_get_multi_info(vp_ctx* ctx, vp_multi_info* out);
-/* Re-cut the slabs at the next vp_bin*: light-axis slices are weighted with this frame's (particle, metavoxel) pairs (fill) and the
- * samples the last vp_raymarch executed in them (ray-march), both measured on the GPUs; collective over all ranks. */
+/* Ask for a new slab cut: the NEXT vp_raymarch also records how many samples it executes per light-axis slice (+3 % on that frame), and
+ * the vp_bin* after it re-cuts the slabs, weighting every slice with its (particle, metavoxel) pairs (fill) and those samples (ray-march),
+ * scaled by the kernel times measured on the GPUs; collective over all ranks (every rank must call it in the same frame).  The first
+ * vp_bin* of a context cuts from the pair histogram alone. */
 int  vp_rebalance(vp_ctx* ctx);
 /* 128 bytes identifying a new RCCL communicator (ncclGetUniqueId): call on ONE process, hand the bytes to every process of the job
  * (any transport: MPI, a TCP store, a file) and pass them in vp_config.rccl_unique_id. */
@@ -324,10 +327,12 @@ int  vp_raymarch_partial_device(vp_ctx* ctx, const vp_camera* cam, const vp_raym
                                 void* d_over, void* d_under, int32_t* phase_mask);
 /* The same with the cross-slab saturation hand-off (the reference's one render target sees every metavoxel, VPR.cs:652-711, so a single GPU
  * stops a ray once it is saturated; a slab alone only knows its own metavoxels):
- *   d_t_in   n_in maps [n_in][H][W] f32 (device): transmittance 1 - alpha of slabs composited IN FRONT of this one; a ray stops once
+ * A hand-off map holds ONE BYTE per pixel: code = floor(-8 log2 t), capped at 255, of a transmittance t = 1 - alpha; it decodes to
+ * 2^(-code/8) >= t (a conservative bound within a factor 2^(1/8)), and the product of maps is the sum of their codes.
+ *   d_t_in   n_in maps [n_in][H][W] u8 (device) of slabs composited IN FRONT of this one; a ray stops once
  *            (1 - dst.a) * prod(t_in) <= 2^-25 (no map: exactly the single-GPU rule).  NULL / 0 = nothing known.
- *   d_t_out0 [H][W] f32: this slab's own transmittance, 1 - alpha of its first image; d_t_out1 (straddling slab): that times
- *            1 - alpha of its phase-B image.  NULL = not wanted.
+ *   d_t_out0 [H][W] u8: this slab's own map, 1 - alpha of its phase-A image; d_t_out1: that times 1 - alpha of its phase-B image (what a
+ *            phase-B slab behind it needs; the two differ only for the slab that straddles zBoundary).  NULL = not wanted.
  * Also accumulates the per-slice sample profile read by vp_read_zsamples. */
 int  vp_raymarch_partial_handoff_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, void* d_over, void* d_under,
                                         int32_t* phase_mask, const void* d_t_in, int32_t n_in, void* d_t_out0, void* d_t_out1);

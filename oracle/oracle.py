@@ -13,7 +13,16 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libvporacle.so")
+_LIB_NATIVE = os.path.join(_HERE, "_build", "libvporacle_native.so")
 _lib = None
+_lib_native = None
+
+
+def build_native() -> str:
+    """The same source compiled -march=native on THIS machine (bench.py's CPU-baseline leg: the portable build targets x86-64-v3
+    because the .so travels to the GPU box; the timed leg should use the box's own cores' ISA).  Never used by the parity tests."""
+    subprocess.run(["make", "-C", _HERE, "-s", "-B", "native"], check=True)      # always rebuilt: a copy built elsewhere must not be reused
+    return _LIB_NATIVE
 
 
 def build(force: bool = False) -> str:
@@ -27,11 +36,7 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+def _declare(_lib):
         _lib.vpo_last_error.restype = C.c_char_p
         _lib.vpo_f16_to_f32.restype = C.c_float
         _lib.vpo_f16_to_f32.argtypes = [C.c_uint16]
@@ -40,6 +45,18 @@ def lib():
         _lib.vpo_sample_cubemap.restype = C.c_float
         _lib.vpo_sample_cubemap.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
         _lib.vpo_sincos_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        return _lib
+
+
+def lib(native: bool = False):
+    global _lib, _lib_native
+    if native:
+        if _lib_native is None:
+            _lib_native = _declare(C.CDLL(build_native()))
+        return _lib_native
+    if _lib is None:
+        build()
+        _lib = _declare(C.CDLL(_LIB_PATH))
     return _lib
 
 
@@ -54,8 +71,8 @@ class OracleError(RuntimeError):
 class Oracle:
     """Same call surface as the product's low-level engine (vpfx_amd.engine.Engine)."""
 
-    def __init__(self, cfg, threads: int = 0, literal: bool = False):
-        self.L = lib()
+    def __init__(self, cfg, threads: int = 0, literal: bool = False, native: bool = False):
+        self.L = lib(native)
         self.h = C.c_void_p()
         self.cfg = cfg
         rc = self.L.vpo_create(C.byref(cfg), C.byref(self.h))

@@ -1,21 +1,34 @@
-"""k_raymarch<PARTIAL> (the multi-GPU variant: OVER and UNDER composites kept apart) against the single-image kernel, whole grid, one GPU."""
-import sys
-import numpy as np
+"""Cost of the slab (partial-image) ray-march against the whole-grid kernel on one GPU: the front half [0, Nz/2) of the benchmark scene
+holds nearly all of the frame's executed samples, so its partial ray-march should cost what the whole-grid kernel costs.
+Run with VPFX_NO_ZPROFILE=1 to take the per-slice sample profile out (A/B).  usage: partial_rm_cost.py [C3] [z0 z1]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-sys.path.insert(0, '.')
-from __graft_entry__ import load_package; load_package()
-from vpfx_amd import scene as S, engine as E
-sc = S.make_scene(sys.argv[1] if len(sys.argv) > 1 else "C3")
-if len(sys.argv) > 2:
-    sc.set_camera(tuple(float(x) for x in sys.argv[2].split(",")))
-g = E.Engine(sc.config())
-g.set_frame(sc.light_to_world, sc.grid_center)
-g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
-g.fill(sc.fill_params())
-a, b, c = (torch.empty((sc.height, sc.width, 4), device="cuda") for _ in range(3))
+from __graft_entry__ import load_package
+load_package()
+from vpfx_amd import engine as E, scene as S
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+sc = S.make_scene(name, cubemap="r8")
+z0, z1 = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, sc.N[2] // 2)
+dev = torch.device("cuda", 0)
 cam, rp = sc.camera(), sc.raymarch_params()
-one, part = [], []
-for it in range(6):
-    g.raymarch_device(cam, rp, a.data_ptr()); g.sync(); one.append(g.last_kernel_ms(2))
-    g.raymarch_partial_device(cam, rp, b.data_ptr(), c.data_ptr()); g.sync(); part.append(g.last_kernel_ms(2))
-print(f"zBoundary {g.z_boundary(cam)}: single image {np.mean(one[1:]):.3f} ms, partial (two images) {np.mean(part[1:]):.3f} ms")
+over, under = (torch.empty((sc.height, sc.width, 4), device=dev) for _ in range(2))
+t_out = torch.empty((2, sc.height, sc.width), device=dev, dtype=torch.uint8)
+res = {}
+for label, slab in (("whole", (0, 0)), ("slab", (z0, z1))):
+    e = E.Engine(sc.config(device=0, slab=slab))
+    e.set_frame(sc.light_to_world, sc.grid_center)
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    e.fill(sc.fill_params())
+    for mode in (("full",) if label == "whole" else ("partial", "handoff")):
+        for _ in range(4):
+            if mode == "full":
+                e.raymarch_device(cam, rp, over.data_ptr())
+            elif mode == "partial":
+                e.raymarch_partial_device(cam, rp, over.data_ptr(), under.data_ptr())
+            else:
+                e.raymarch_partial_handoff_device(cam, rp, over.data_ptr(), under.data_ptr(), 0, 0, t_out[0].data_ptr(), t_out[1].data_ptr())
+        e.sync()
+        res[f"{label}/{mode}"] = (round(e.last_kernel_ms(2), 4), e.stats()["samples"])
+    e.close()
+print(f"{name} slab [{z0},{z1}) zprofile={'off' if os.environ.get('VPFX_NO_ZPROFILE') == '1' else 'on'}:", res)

@@ -1,68 +1,116 @@
-"""Predict the N-GPU frame time of the slab pipeline from ONE GPU: run the N slab engines of `bench.py --gpus N` one after the
-other on this GPU (same slab cut, same kernels, each engine alone on the device), take the per-stage kernel times of every slab,
-and combine them as the pipeline does (stage barriers at the two collectives):
-    t_N = max_r(bin_r + fill_local_r) + t_allgather(tau) + max_r(finish_r) + max_r(raymarch_partial_r) + t_exchange(images) + blend
-The collective terms are xGMI estimates (7 links x ~50 GB/s usable per GPU + ~40 us software latency per collective), stated in
-the output; everything else is measured.  usage: scaling_model.py [C3] [r8|f32]"""
+"""Predict the N-GPU frame time of the in-library fan-out (csrc/multi.cpp) from ONE GPU.
+
+For every (N, hand-off groups):
+  1. the LIBRARY cuts the slabs: a fan-out context with N slabs on this GPU (VP_MULTI_PEER_COPY test hook) renders three frames,
+     re-balancing twice from its measured work histograms -- exactly what `bench.py --gpus N` does in its warm-up; its image is checked
+     against the single-GPU frame and its slab cut, compositing chain and hand-off groups are taken over;
+  2. the N slab contexts are then run ONE AFTER THE OTHER, each alone on the GPU (the kernels of concurrent ranks would otherwise share
+     the device and stretch each other), with the same cut, the same kernels and the real hand-off maps of the slabs in front
+     (vp_raymarch_partial_handoff_device), front to back along the chain;
+  3. the per-rank kernel times are combined as the pipeline does:
+        t_N = max_r(bin_r + fill_local_r) + t(tau all-gather) + max_r(finish_r)
+            + sum over hand-off groups g of max_{r in g}(raymarch_r) + (groups - 1) * t(hand-off hop) + t(image exchange) + t(blend)
+The exchange terms are xGMI ESTIMATES (one link ~50 GB/s usable per direction, seven links per GPU, ~40 us software latency per RCCL call),
+stated in the output; everything else is measured.  The host side is the library's worker threads (one per GPU), not modelled: each
+issues ~25 launches per frame.  usage: scaling_model.py [C3] [r8|f32]"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from __graft_entry__ import load_package
 load_package()
-from vpfx_amd import engine as E, parallel as PAR, scene as S
+from vpfx_amd import abi, engine as E, scene as S
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cube = sys.argv[2] if len(sys.argv) > 2 else "r8"
 sc = S.make_scene(name, cubemap=cube)
 dev = torch.device("cuda", 0)
+cam, rp = sc.camera(), sc.raymarch_params()
+img = torch.empty((sc.height, sc.width, 4), device=dev)
 probe = E.Engine(sc.config())
 probe.set_frame(sc.light_to_world, sc.grid_center)
 probe.bin(sc.particles, sc.layout, sc.psys_local_to_world)
-counts = probe.bin_counts()
-mvpos = probe.mv_positions()
 probe.fill(sc.fill_params())
-img = torch.empty((sc.height, sc.width, 4), device=dev)
 for _ in range(3):
-    probe.bin_resident(); probe.fill(sc.fill_params()); probe.raymarch_device(sc.camera(), sc.raymarch_params(), img.data_ptr())
+    probe.bin_resident(); probe.fill(sc.fill_params()); probe.raymarch_device(cam, rp, img.data_ptr())
 probe.sync()
 one = dict(bin=probe.last_kernel_ms(0), fill=probe.last_kernel_ms(1), rm=probe.last_kernel_ms(2), samples=probe.stats()["samples"])
+zb = probe.z_boundary(cam)
+ref = img.clone()
 probe.close()
-weights, fill_w, rm_w = PAR.slice_costs(counts, mvpos, sc.cam_pos, sc.mv_scale, sc.height, np.radians(sc.fov_y_deg), sc.steps)
-print(f"slice-cost model: fill {sum(fill_w):.2f} ms, ray-march {sum(rm_w):.2f} ms without cross-slab early-out")
+one_ms = one["bin"] + one["fill"] + one["rm"]
+print(f"1 GPU: bin {one['bin']:.3f} fill {one['fill']:.3f} ray-march {one['rm']:.3f} = {one_ms:.3f} ms, {one['samples'] / 1e6:.0f} M samples, zBoundary {zb}")
 npix = sc.width * sc.height
-lm_bytes = sc.N[0] * sc.nv * sc.N[1] * sc.nv * 4
-LINK = 7 * 50e9      # bytes/s a GPU can move over its seven xGMI links (conservative)
-LAT = 40e-6          # software + launch latency per collective
-out = {"config": name, "cubemap": cube, "one_gpu_ms": one, "predictions": {}}
+lm = (sc.N[1] * sc.nv, sc.N[0] * sc.nv)
+lm_bytes = lm[0] * lm[1] * 4
+LINK1 = 50e9         # bytes/s over ONE xGMI link, one direction (conservative; 76.8 GB/s nominal)
+LAT = 40e-6          # software + launch latency per RCCL call
+out = {"config": name, "cubemap": cube, "one_gpu_ms": one, "assumptions": {"xgmi_link_GBps": LINK1 / 1e9, "rccl_call_latency_us": LAT * 1e6},
+       "predictions": {}}
+
+
+def frame(e, first=False):
+    e.bin_resident(); e.fill(sc.fill_params()); e.raymarch_device(cam, rp, img.data_ptr())
+
+
 for world in (2, 4, 8):
-    bounds = PAR.choose_slabs(sc.N[2], world, fill_w, rm_w)
-    rows = []
-    for r in range(world):
-        e = E.Engine(sc.config(device=0, slab=bounds[r]))
-        e.set_frame(sc.light_to_world, sc.grid_center)
-        e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
-        h = PAR.HipSlabEngine(e, dev)
-        tau_all = torch.ones((world,) + h.lm_shape, device=dev)
-        for _ in range(3):
-            h.bin_resident(); h.fill_local(sc.fill_params()); h.fill_finish_gathered(tau_all, r, world); h.raymarch_partial(sc.camera(), sc.raymarch_params())
-        e.sync()
-        st = e.stats()
-        rows.append(dict(slab=bounds[r], bin=e.last_kernel_ms(0), fill_local=e.last_kernel_ms(1), finish=e.last_kernel_ms(3), rm=e.last_kernel_ms(2),
-                         samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"]))
-        e.close(); del h, tau_all
+    for groups in sorted({1, 2, world}):
+        # 1. the library's own cut, chain and groups
+        m = E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY, rm_groups=groups))
+        m.set_frame(sc.light_to_world, sc.grid_center)
+        m.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+        frame(m)
+        for _ in range(2):
+            m.rebalance(); frame(m)
+        frame(m)                       # (the cut asked for by the second vp_rebalance takes effect at this frame's bin)
+        m.sync()
+        err = float((img - ref).abs().max().item())
+        info = m.multi_info()
+        m.close()
         torch.cuda.empty_cache()
-    t_tau = LAT + (world - 1) * lm_bytes / LINK
-    t_img = 2 * LAT + 2 * (world - 1) / world * npix * 16 / LINK      # all-to-all of pieces + gather of the finished pieces
-    t_blend = 0.02e-3 * 1e3 / 1e3
-    t = (max(x["bin"] + x["fill_local"] for x in rows) + max(x["finish"] for x in rows) + max(x["rm"] for x in rows)) * 1e-3 + t_tau + t_img + t_blend
-    out["predictions"][world] = {
-        "slabs": bounds, "per_rank": rows, "t_allgather_tau_ms": t_tau * 1e3, "t_image_exchange_ms": t_img * 1e3,
-        "predicted_ms_per_step": t * 1e3, "speedup_vs_1gpu": (one["bin"] + one["fill"] + one["rm"]) / (t * 1e3),
-        "samples_executed_all_ranks": sum(x["samples"] for x in rows),
-        "host_overhead_note": "plus the Python/ctypes/torch.distributed host path per frame (~0.2-0.4 ms, not modelled)"}
-    print(f"N={world}: predicted {t * 1e3:.2f} ms/step ({out['predictions'][world]['speedup_vs_1gpu']:.2f}x of the 1-GPU kernels {one['bin'] + one['fill'] + one['rm']:.2f} ms); "
-          f"max fill_local {max(x['fill_local'] for x in rows):.2f} finish {max(x['finish'] for x in rows):.2f} rm {max(x['rm'] for x in rows):.2f}; "
-          f"samples all ranks {sum(x['samples'] for x in rows) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M on one GPU")
-os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open(f"gpurun_out/scaling_model_{name}_{cube}.json", "w"), indent=1)
+        cuts, chain, group_of = info["slab_cuts"], info["chain"], info["group_of"]
+        # 2. every slab alone on the GPU, front to back, with the real hand-off maps
+        rows, maps = {}, {}
+        for r in chain:
+            e = E.Engine(sc.config(device=0, slab=(cuts[r], cuts[r + 1])))
+            e.set_frame(sc.light_to_world, sc.grid_center)
+            e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+            tau_all = torch.ones((world,) + lm, device=dev)
+            front = [s for s in chain if group_of[s] < group_of[r]]
+            a_only = cuts[r + 1] - 1 <= zb
+            t_in = torch.stack([maps[s][0 if a_only else 1] for s in front]).contiguous() if front else None
+            over, under = torch.empty_like(img), torch.empty_like(img)
+            t_out = torch.empty((2, sc.height, sc.width), device=dev, dtype=torch.uint8)
+            for _ in range(3):
+                e.bin_resident(); e.fill_local(sc.fill_params(), tau_all[r].data_ptr()); e.fill_finish_gathered(tau_all.data_ptr(), r, world)
+                e.raymarch_partial_handoff_device(cam, rp, over.data_ptr(), under.data_ptr(), t_in.data_ptr() if front else 0, len(front),
+                                                  t_out[0].data_ptr(), t_out[1].data_ptr())
+            e.sync()
+            st = e.stats()
+            maps[r] = (t_out[0].clone(), t_out[1].clone())
+            rows[r] = dict(slab=[cuts[r], cuts[r + 1]], group=group_of[r], bin=e.last_kernel_ms(0), fill_local=e.last_kernel_ms(1), finish=e.last_kernel_ms(3),
+                           rm=e.last_kernel_ms(2), samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"])
+            e.close(); del tau_all, over, under
+            torch.cuda.empty_cache()
+        # 3. the pipeline
+        t_tau = LAT + lm_bytes / LINK1                                   # every rank receives the other ranks' maps over separate links
+        t_hop = LAT + npix / LINK1                                       # one byte per pixel per map, senders on separate links
+        piece = npix * 16 / world
+        t_img = 2 * (LAT + piece / LINK1)                                # all-to-all of pieces, then the gather on the display rank
+        t_blend = 0.02e-3
+        G = max(group_of) + 1
+        rm_groups = [max(rows[r]["rm"] for r in chain if group_of[r] == g) for g in range(G)]
+        t = (max(x["bin"] + x["fill_local"] for x in rows.values()) + max(x["finish"] for x in rows.values()) + sum(rm_groups)) * 1e-3 \
+            + t_tau + (G - 1) * t_hop + t_img + t_blend
+        key = f"{world}gpu_{groups}groups"
+        out["predictions"][key] = {
+            "world": world, "rm_groups": groups, "slab_cuts": cuts, "chain": chain, "group_of": group_of, "per_rank": [rows[r] for r in range(world)],
+            "max_abs_rgba_diff_vs_1gpu_frame": err, "t_allgather_tau_ms": t_tau * 1e3, "t_handoff_hop_ms": t_hop * 1e3, "t_image_exchange_ms": t_img * 1e3,
+            "raymarch_ms_per_group": rm_groups, "predicted_ms_per_step": t * 1e3, "speedup_vs_1gpu": one_ms / (t * 1e3),
+            "samples_executed_all_ranks": sum(x["samples"] for x in rows.values())}
+        print(f"N={world} groups={groups}: predicted {t * 1e3:.2f} ms/step ({one_ms / (t * 1e3):.2f}x); cut {cuts}; "
+              f"max bin+fill_local {max(x['bin'] + x['fill_local'] for x in rows.values()):.2f} finish {max(x['finish'] for x in rows.values()):.2f} "
+              f"rm per group {[round(x, 3) for x in rm_groups]} (max single {max(x['rm'] for x in rows.values()):.3f}); exchanges {1e3 * (t_tau + (G - 1) * t_hop + t_img):.2f}; "
+              f"samples {sum(x['samples'] for x in rows.values()) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M; fan-out image err {err:.1e}", flush=True)
+os.makedirs("gpurun_out/r3", exist_ok=True)
+json.dump(out, open(f"gpurun_out/r3/scaling_model_{name}_{cube}.json", "w"), indent=1)

@@ -121,3 +121,13 @@ def test_demo_frame_matches_the_python_binding_and_the_oracle(tmp_path):
     assert abs(nums["sum_rgb"] - float(imgs[0][..., :3].astype(np.float64).sum())) <= 1e-3
     assert abs(nums["sum_lightmap"] - float(lm.astype(np.float64).sum())) <= 1e-3
     assert np.abs(imgs[0] - imgs[1]).max() <= 1e-3                      # ... and the C caller's frame is the oracle's frame
+    # the same C program on a fan-out context: the device list is the only thing the host adds (here: 2 slabs on this GPU through the
+    # library's peer-copy test hook); same statistics, same frame up to the reassociated light product (<= 2e-5 per pixel)
+    r2 = subprocess.run([_build_demo(tmp_path), str(P), "2", "share"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    nums2 = {k: float(v) for k, v in re.findall(r"(\w+) (-?[\d.]+)", r2.stdout)}
+    for key in ("particles", "occupied_mv", "pairs", "voxels"):
+        assert nums2[key] == nums[key], key
+    assert nums2["ranks"] == 2 and nums2["rccl_ranks"] == 0 and "slabs [0," in r2.stdout
+    assert abs(nums2["sum_alpha"] - nums["sum_alpha"]) <= 2e-5 * W * H and abs(nums2["sum_rgb"] - nums["sum_rgb"]) <= 6e-5 * W * H
+    assert abs(nums2["sum_lightmap"] - nums["sum_lightmap"]) <= 1e-4 * abs(nums["sum_lightmap"])

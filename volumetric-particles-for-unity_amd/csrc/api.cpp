@@ -257,6 +257,7 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
     c->cfg = *cfg;
     c->device = dev;
     { const char* hook = getenv("VPFX_TEST_CHAIN_TIMEOUT"); c->test_chain_timeout = hook && hook[0] == '1'; }
+    { const char* sw = getenv("VPFX_NO_ZPROFILE"); c->no_zprofile = sw && sw[0] == '1'; }
     c->n3 = (size_t)cfg->num_mv[0] * cfg->num_mv[1] * cfg->num_mv[2];
     // identity frame until vp_set_frame
     memset(c->L, 0, sizeof c->L); c->L[0] = c->L[5] = c->L[10] = c->L[15] = 1.f;
@@ -277,7 +278,7 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, (int4**)&c->d_scan_totals, (c->n3 + 1023) / 1024 + 1)) ||
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
-        (rc = dev_alloc(c, &c->d_zsamples, (size_t)cfg->num_mv[2])) ||
+        (rc = dev_alloc(c, &c->d_zsamples, (size_t)VPFX_ZPROF_COPIES * cfg->num_mv[2])) ||
         (rc = dev_alloc(c, &c->d_cam_rows, 12)) || (rc = dev_alloc(c, &c->d_tile_order, 2 * ((size_t)rm_num_super_tiles(cfg->width, cfg->height) + 8))))
         return fail(rc);
     if (hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -650,9 +651,9 @@ VP_EXPORT int vp_raymarch_partial_handoff_device(vp_ctx* c, const vp_camera* cam
     float* keep = c->d_scene_depth;
     if (!rp->scene_depth && c->n_occluders == 0) c->d_scene_depth = nullptr;
     RmHandoff ho{};
-    ho.t_in = n_in > 0 ? (const float*)d_t_in : nullptr; ho.n_in = n_in; ho.plane = (size_t)c->cfg.width * c->cfg.height;
-    ho.t_out0 = (float*)d_t_out0; ho.t_out1 = (float*)d_t_out1; ho.zsamples = c->d_zsamples;
-    VP_HIP(hipMemsetAsync(c->d_zsamples, 0, (size_t)c->g.Nz * sizeof(unsigned), c->stream));
+    ho.t_in = n_in > 0 ? (const uint8_t*)d_t_in : nullptr; ho.n_in = n_in; ho.plane = (size_t)c->cfg.width * c->cfg.height;
+    ho.t_out0 = (uint8_t*)d_t_out0; ho.t_out1 = (uint8_t*)d_t_out1; ho.zsamples = c->no_zprofile ? nullptr : c->d_zsamples;
+    VP_HIP(hipMemsetAsync(c->d_zsamples, 0, (size_t)VPFX_ZPROF_COPIES * c->g.Nz * sizeof(unsigned), c->stream));
     rc = launch_raymarch(c, k, (float*)d_over, (float*)d_under, &ho);
     c->d_scene_depth = keep;
     return rc;
@@ -664,14 +665,27 @@ VP_EXPORT int vp_read_zsamples(vp_ctx* c, int64_t* samples_per_z)
     if (!samples_per_z) return vp_fail(c, VP_ERR_BAD_ARG, "vp_read_zsamples: null output");
     VP_NO_FANOUT(c, "vp_read_zsamples");
     int rc = ensure_device(c); if (rc) return rc;
-    { int rcs = stream_sync(c); if (rcs) return rcs; }
+    long long* tmp = (long long*)malloc((size_t)c->g.Nz * sizeof(long long));
+    if (!tmp) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
+    rc = api_read_zsamples(c, tmp, true);
+    for (int i = 0; i < c->g.Nz; ++i) samples_per_z[i] = tmp[i];
+    free(tmp);
+    return rc;
+}
+
+int api_read_zsamples(vp_ctx* c, long long* out, bool sync)
+{
+    if (sync) { int rcs = stream_sync(c); if (rcs) return rcs; }
     const int nz = c->g.Nz;
-    unsigned* h = (unsigned*)malloc((size_t)nz * sizeof(unsigned));
+    const size_t n = (size_t)VPFX_ZPROF_COPIES * nz;
+    unsigned* h = (unsigned*)malloc(n * sizeof(unsigned));
     if (!h) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
-    hipError_t e = hipMemcpy(h, c->d_zsamples, (size_t)nz * sizeof(unsigned), hipMemcpyDeviceToHost);
-    for (int i = 0; i < nz; ++i) samples_per_z[i] = h[i];
+    hipError_t e = hipMemcpyAsync(h, c->d_zsamples, n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int z = 0; z < nz; ++z) out[z] = 0;
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) out[i % nz] += h[i];
     free(h);
-    if (e != hipSuccess) return vp_fail(c, VP_ERR_HIP, "vp_read_zsamples: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return vp_fail(c, VP_ERR_HIP, "zsamples read-back: %s", hipGetErrorString(e));
     return VP_OK;
 }
 

@@ -245,6 +245,46 @@ void min_max_partition(int nz, int world, const std::vector<double>& w, int* cut
     for (int k = world; k >= 1; --k) { z = arg[k][z]; cuts[k - 1] = z; }
 }
 
+// Exact optimum of  W * max_r F_r + max_r R_r  over contiguous partitions into `world` slabs of >= 1 slice (F, R = per-slice costs of two
+// pipeline stages that each wait for their slowest slab): for every candidate bound B on the first maximum (all interval sums of F), a
+// min-max DP of R over the partitions whose slabs all keep F <= B; the best B wins.  nz^2 / 2 bounds x world x nz^2 steps: ~4 M at nz = 32.
+double two_maxima_partition(int nz, int world, const std::vector<double>& F, const std::vector<double>& R, double W, int* cuts)
+{
+    std::vector<double> pf(nz + 1, 0.0), pr(nz + 1, 0.0);
+    for (int z = 0; z < nz; ++z) { pf[z + 1] = pf[z] + std::max(F[z], 0.0); pr[z + 1] = pr[z] + std::max(R[z], 0.0); }
+    std::vector<double> bounds;
+    for (int y = 0; y < nz; ++y)
+        for (int z = y + 1; z <= nz; ++z) bounds.push_back(pf[z] - pf[y]);
+    std::sort(bounds.begin(), bounds.end());
+    bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
+    const double INF = 1e300;
+    double best = INF;
+    std::vector<std::vector<double>> dp(world + 1, std::vector<double>(nz + 1));
+    std::vector<std::vector<int>> arg(world + 1, std::vector<int>(nz + 1));
+    std::vector<int> cand(world + 1);
+    for (double B : bounds) {
+        if (W * B >= best) break;                            // bounds ascend: no later one can win
+        for (auto& row : dp) std::fill(row.begin(), row.end(), INF);
+        dp[0][0] = 0.0;
+        for (int k = 1; k <= world; ++k)
+            for (int z = k; z <= nz - (world - k); ++z)
+                for (int y = k - 1; y < z; ++y) {
+                    if (dp[k - 1][y] >= INF || pf[z] - pf[y] > B) continue;
+                    const double v = std::max(dp[k - 1][y], pr[z] - pr[y]);
+                    if (v < dp[k][z]) { dp[k][z] = v; arg[k][z] = y; }
+                }
+        if (dp[world][nz] >= INF) continue;
+        int z = nz;
+        cand[world] = nz;
+        for (int k = world; k >= 1; --k) { z = arg[k][z]; cand[k - 1] = z; }
+        double fmax = 0.0;
+        for (int r = 0; r < world; ++r) fmax = std::max(fmax, pf[cand[r + 1]] - pf[cand[r]]);
+        const double t = W * fmax + dp[world][nz];
+        if (t < best - 1e-12) { best = t; for (int i = 0; i <= world; ++i) cuts[i] = cand[i]; }
+    }
+    return best;
+}
+
 }  // namespace
 
 void hl_chain_groups(int world, int rm_groups, int* group_of_pos)
@@ -255,10 +295,11 @@ void hl_chain_groups(int world, int rm_groups, int* group_of_pos)
 
 // The frame waits for the slowest slab in the fill (x 1.3: local pass + finish pass of the split fill) and, in the ray-march, for the
 // slowest slab of every hand-off group in turn (groups run one after the other; within a group the slabs march concurrently).  The cut
-// that balances fill + ray-march per slice need not minimise that, so the candidates are the optimal min-max partitions of
-// fill + alpha * raymarch for a few alpha (0 = fill only ... raymarch only) and the one with the smallest modelled frame wins (ties: the
-// earliest candidate, i.e. the more fill-balanced).  Groups are taken in rank order here (exact for a camera outside the grid along the
-// light axis, the benchmark's case; a camera inside the grid reorders the chain around the straddling slab).
+// that balances fill + ray-march per slice need not minimise that.  Without a hand-off (one group) the modelled frame is a sum of two
+// maxima, minimised exactly (two_maxima_partition).  With groups the candidates are that cut and the optimal min-max partitions of
+// fill + alpha * raymarch for a few alpha (0 = fill only ... raymarch only), and the one with the smallest modelled frame wins (ties: the
+// earliest candidate).  Groups are taken in rank order here (exact for a camera outside the grid along the light axis, the benchmark's
+// case; a camera inside the grid reorders the chain around the straddling slab).
 void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms, int rm_groups, int* cuts)
 {
     if (world > nz) world = nz;
@@ -266,16 +307,19 @@ void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms
     if (!fill_ms && !rm_ms) { min_max_partition(nz, world, w, cuts); return; }
     std::vector<int> gp(world);
     hl_chain_groups(world, rm_groups, gp.data());
-    const double alphas[] = {0.0, 0.25, 0.5, 1.0, 2.0, 4.0, -1.0};
+    const double alphas[] = {-2.0, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0, -1.0};
     double best_t = 1e300;
     std::vector<int> cand(world + 1);
     bool have = false;
+    std::vector<double> Fv(nz), Rv(nz);
+    for (int z = 0; z < nz; ++z) { Fv[z] = fill_ms ? fill_ms[z] : 0.0; Rv[z] = rm_ms ? rm_ms[z] : 0.0; }
     for (double a : alphas) {
-        for (int z = 0; z < nz; ++z) {
-            const double f = fill_ms ? fill_ms[z] : 0.0, r = rm_ms ? rm_ms[z] : 0.0;
-            w[z] = a < 0.0 ? r : f + a * r;
+        if (a == -2.0) {
+            (void)two_maxima_partition(nz, world, Fv, Rv, 1.3, cand.data());         // the exact optimum for one group
+        } else {
+            for (int z = 0; z < nz; ++z) w[z] = a < 0.0 ? Rv[z] : Fv[z] + a * Rv[z];
+            min_max_partition(nz, world, w, cand.data());
         }
-        min_max_partition(nz, world, w, cand.data());
         double fmax = 0.0;
         std::vector<double> gmax(world, 0.0);
         for (int r = 0; r < world; ++r) {

@@ -105,8 +105,8 @@ struct Kid {
     ncclComm_t comm = nullptr;
     float* d_tau_all = nullptr;       // [world][LH][LW]: all-gathered slab transmittance maps (own slot written by the local fill pass)
     float* d_img[2] = {nullptr, nullptr};   // partial images of the slab (phase-A composite, phase-B composite), padded to whole pieces
-    float* d_tmaps = nullptr;         // [world][H][W] received transmittance maps of the slabs in front
-    float* d_tout[2] = {nullptr, nullptr};  // own transmittance: 1 - alpha(A), (1 - alpha(A)) (1 - alpha(B))
+    uint8_t* d_tmaps = nullptr;       // [world][H][W] received hand-off maps of the slabs in front (one byte per pixel, RmHandoff)
+    uint8_t* d_tout[2] = {nullptr, nullptr};  // own maps: 1 - alpha(A), (1 - alpha(A)) (1 - alpha(B))
     float* d_pieces = nullptr;        // tiles: [world + 1][piece][4] received pieces; all-gather: [world + 1][pixpad][4] whole images
     float* d_piece_out = nullptr;     // [piece][4] this rank's blended piece
     float* d_final = nullptr;         // display rank: [pixpad][4]
@@ -120,7 +120,7 @@ struct Kid {
 
 struct Mail { void* dst = nullptr; size_t bytes = 0; bool posted = false, done = false; hipEvent_t ev = nullptr; };
 
-struct P2P { bool send; int peer; void* ptr; size_t count; };      // count in floats
+struct P2P { bool send; int peer; void* ptr; size_t bytes; };
 
 }  // namespace
 
@@ -131,7 +131,7 @@ struct vp_multi {
     int rccl_ranks = 0;
     std::vector<Kid> kids;
     std::vector<int> cuts;                    // [world + 1]
-    bool need_plan = true, have_profile = false;
+    bool need_plan = true, have_profile = false, want_profile = false;
     int chain[VP_MAX_RANKS] = {}, group_of[VP_MAX_RANKS] = {};
     size_t npix = 0, piece = 0, pixpad = 0, lm = 0;
     // worker pool: one persistent thread per local rank (none when there is only one)
@@ -233,7 +233,7 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
         Rccl& R = rccl();
         VP_NCCL(R.GroupStart());
         for (const P2P& o : ops) {
-            const ncclResult_t r = o.send ? R.Send(o.ptr, o.count, ncclFloat, o.peer, k.comm, k.stream) : R.Recv(o.ptr, o.count, ncclFloat, o.peer, k.comm, k.stream);
+            const ncclResult_t r = o.send ? R.Send(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, k.stream) : R.Recv(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, k.stream);
             if (r != ncclSuccess) { (void)R.GroupEnd(); return vp_fail(c, VP_ERR_RCCL, "ncclSend/ncclRecv failed: %s", R.GetErrorString(r)); }
         }
         VP_NCCL(R.GroupEnd());
@@ -247,7 +247,7 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
             if (!o.send) {
                 const auto key = std::make_tuple(o.peer, k.rank, k.seq_from[o.peer]++);
                 Mail& ml = M->box[key];
-                ml.dst = o.ptr; ml.bytes = o.count * sizeof(float); ml.posted = true;
+                ml.dst = o.ptr; ml.bytes = o.bytes; ml.posted = true;
                 mine.push_back(key);
             }
         M->mcv.notify_all();
@@ -260,12 +260,12 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
                 std::unique_lock<std::mutex> lk(M->mm);
                 M->mcv.wait(lk, [&] { auto it = M->box.find(key); return it != M->box.end() && it->second.posted; });
                 Mail& ml = M->box[key];
-                if (ml.bytes != o.count * sizeof(float)) return vp_fail(c, VP_ERR_STATE, "loopback exchange: size mismatch between ranks %d and %d", k.rank, o.peer);
+                if (ml.bytes != o.bytes) return vp_fail(c, VP_ERR_STATE, "loopback exchange: size mismatch between ranks %d and %d", k.rank, o.peer);
                 dst = ml.dst;
             }
             hipEvent_t ev = nullptr;
             VP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            VP_HIP(hipMemcpyAsync(dst, o.ptr, o.count * sizeof(float), hipMemcpyDefault, k.stream));
+            VP_HIP(hipMemcpyAsync(dst, o.ptr, o.bytes, hipMemcpyDefault, k.stream));
             VP_HIP(hipEventRecord(ev, k.stream));
             {
                 std::lock_guard<std::mutex> lk(M->mm);
@@ -301,8 +301,8 @@ int all_gather_inplace(vp_multi* M, Kid& k, float* buf, size_t count)
         if (r != k.rank) {
             Kid* peer = local_kid(M, r);
             if (!peer) return vp_fail(c, VP_ERR_STATE, "loopback exchange needs every rank in this process");
-            ops.push_back(P2P{false, r, buf + (size_t)r * count, count});
-            ops.push_back(P2P{true, r, buf + (size_t)k.rank * count, count});
+            ops.push_back(P2P{false, r, buf + (size_t)r * count, count * sizeof(float)});
+            ops.push_back(P2P{true, r, buf + (size_t)k.rank * count, count * sizeof(float)});
         }
     return p2p_batch(M, k, ops);
 }
@@ -350,9 +350,8 @@ int plan_slabs(vp_multi* M, Kid& k)
         std::vector<float> all((size_t)world * stride, 0.f);
         if (M->have_profile) {
             k.h_xfer.assign(stride, 0.f);
-            std::vector<unsigned> zs(nz);
-            VP_HIP(hipMemcpyAsync(zs.data(), c->d_zsamples, (size_t)nz * sizeof(unsigned), hipMemcpyDeviceToHost, k.stream));
-            VP_HIP(hipStreamSynchronize(k.stream));
+            std::vector<long long> zs(nz);
+            rc = api_read_zsamples(c, zs.data(), false); if (rc) return rc;
             for (int z = 0; z < nz; ++z) k.h_xfer[z] = (float)zs[z];
             float ms = 0.f;
             if (c->ev_valid[1] && hipEventElapsedTime(&ms, c->ev[1][0], c->ev[1][1]) == hipSuccess) k.h_xfer[nz] = ms;
@@ -424,7 +423,7 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     P->device = devs[0];
     M->parent = P;
     M->world = world; M->nlocal = nlocal; M->first_rank = first; M->flags = cfg->multi_flags;
-    M->groups = cfg->rm_groups > 0 ? std::min(cfg->rm_groups, world) : (world >= 4 ? 2 : 1);
+    M->groups = cfg->rm_groups > 0 ? std::min(cfg->rm_groups, world) : 1;
     M->use_rccl = !loopback;
     M->npix = (size_t)cfg->width * cfg->height;
     M->piece = (M->npix + world - 1) / world;
@@ -456,12 +455,13 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
         k.c->stream = k.stream;
         const size_t img = M->pixpad * 4, plane = M->npix;
         const size_t pieces = gather_all ? (size_t)(world + 1) * M->pixpad * 4 : (size_t)(world + 1) * M->piece * 4;
-        struct { float** p; size_t n; } allocs[] = {
-            {&k.d_tau_all, (size_t)world * M->lm}, {&k.d_img[0], img}, {&k.d_img[1], img}, {&k.d_tmaps, (size_t)world * plane},
-            {&k.d_tout[0], plane}, {&k.d_tout[1], plane}, {&k.d_pieces, pieces}, {&k.d_piece_out, M->piece * 4},
-            {&k.d_final, k.rank == 0 ? img : 4}, {&k.d_xfer, (size_t)world * (cfg->num_mv[2] + 8)}};
+        struct { void** p; size_t n; } allocs[] = {
+            {(void**)&k.d_tau_all, (size_t)world * M->lm * 4}, {(void**)&k.d_img[0], img * 4}, {(void**)&k.d_img[1], img * 4},
+            {(void**)&k.d_tmaps, (size_t)world * plane}, {(void**)&k.d_tout[0], plane}, {(void**)&k.d_tout[1], plane},
+            {(void**)&k.d_pieces, pieces * 4}, {(void**)&k.d_piece_out, M->piece * 16}, {(void**)&k.d_final, (k.rank == 0 ? img : 4) * 4},
+            {(void**)&k.d_xfer, (size_t)world * (cfg->num_mv[2] + 8) * 4}};
         for (auto& a : allocs)
-            if (hipMalloc((void**)a.p, a.n * sizeof(float)) != hipSuccess) { k.c->err = "hipMalloc of the exchange buffers failed"; return fail(VP_ERR_OOM, "exchange buffers"); }
+            if (hipMalloc(a.p, a.n) != hipSuccess) { k.c->err = "hipMalloc of the exchange buffers failed"; return fail(VP_ERR_OOM, "exchange buffers"); }
         // the padding pixels of the partial images are exchanged and blended like any others: keep them defined
         if (hipMemsetAsync(k.d_img[0], 0, img * sizeof(float), k.stream) != hipSuccess || hipMemsetAsync(k.d_img[1], 0, img * sizeof(float), k.stream) != hipSuccess)
             return fail(VP_ERR_HIP, "hipMemset");
@@ -634,8 +634,8 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         if (!rp->scene_depth && c->n_occluders == 0) c->d_scene_depth = nullptr;
         RmHandoff ho{};
         ho.t_in = n_in ? k.d_tmaps : nullptr; ho.n_in = n_in; ho.plane = M->npix;
-        ho.t_out0 = k.d_tout[0]; ho.t_out1 = k.d_tout[1]; ho.zsamples = c->d_zsamples;
-        hipError_t he = hipMemsetAsync(c->d_zsamples, 0, (size_t)c->g.Nz * sizeof(unsigned), k.stream);
+        ho.t_out0 = k.d_tout[0]; ho.t_out1 = k.d_tout[1]; ho.zsamples = (M->want_profile && !c->no_zprofile) ? c->d_zsamples : nullptr;   // the profile costs ~3 %: only when a re-cut was asked for
+        hipError_t he = hipMemsetAsync(c->d_zsamples, 0, (size_t)VPFX_ZPROF_COPIES * c->g.Nz * sizeof(unsigned), k.stream);
         r = he == hipSuccess ? launch_raymarch(c, kc, k.d_img[0], k.d_img[1], &ho) : vp_fail(c, VP_ERR_HIP, "hipMemsetAsync failed");
         c->d_scene_depth = keep;
         if (r) return r;
@@ -656,12 +656,12 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
             ops.clear();
             for (int j = 0; j < world; ++j)
                 if (j != k.rank) {
-                    ops.push_back(P2P{false, j, k.d_pieces + (size_t)j * pc, pc});
-                    ops.push_back(P2P{true, j, primary + (size_t)j * pc, pc});
+                    ops.push_back(P2P{false, j, k.d_pieces + (size_t)j * pc, pc * sizeof(float)});
+                    ops.push_back(P2P{true, j, primary + (size_t)j * pc, pc * sizeof(float)});
                 }
             if (strad >= 0) {
-                if (k.rank == strad) { for (int j = 0; j < world; ++j) if (j != k.rank) ops.push_back(P2P{true, j, second + (size_t)j * pc, pc}); }
-                else ops.push_back(P2P{false, strad, k.d_pieces + (size_t)world * pc, pc});
+                if (k.rank == strad) { for (int j = 0; j < world; ++j) if (j != k.rank) ops.push_back(P2P{true, j, second + (size_t)j * pc, pc * sizeof(float)}); }
+                else ops.push_back(P2P{false, strad, k.d_pieces + (size_t)world * pc, pc * sizeof(float)});
             }
             r = p2p_batch(M, k, ops); if (r) return r;
             r = copy_on_stream(k, k.d_pieces + (size_t)k.rank * pc, primary + (size_t)k.rank * pc, pc * sizeof(float)); if (r) return r;
@@ -670,8 +670,8 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
             r = launch_blend(c, images, plan_kind, n_plan, k.d_piece_out, M->piece); if (r) return r;
             // gather the finished pieces on the display rank
             ops.clear();
-            if (k.rank == 0) { for (int j = 1; j < world; ++j) ops.push_back(P2P{false, j, k.d_final + (size_t)j * pc, pc}); }
-            else ops.push_back(P2P{true, 0, k.d_piece_out, pc});
+            if (k.rank == 0) { for (int j = 1; j < world; ++j) ops.push_back(P2P{false, j, k.d_final + (size_t)j * pc, pc * sizeof(float)}); }
+            else ops.push_back(P2P{true, 0, k.d_piece_out, pc * sizeof(float)});
             r = p2p_batch(M, k, ops); if (r) return r;
             if (k.rank == 0) { r = copy_on_stream(k, k.d_final, k.d_piece_out, pc * sizeof(float)); if (r) return r; }
         } else {
@@ -681,8 +681,8 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
             r = all_gather_inplace(M, k, k.d_pieces, ic); if (r) return r;
             ops.clear();
             if (strad >= 0 && strad != 0) {
-                if (k.rank == strad) ops.push_back(P2P{true, 0, second, ic});
-                else if (k.rank == 0) ops.push_back(P2P{false, strad, k.d_pieces + (size_t)world * ic, ic});
+                if (k.rank == strad) ops.push_back(P2P{true, 0, second, ic * sizeof(float)});
+                else if (k.rank == 0) ops.push_back(P2P{false, strad, k.d_pieces + (size_t)world * ic, ic * sizeof(float)});
             }
             r = p2p_batch(M, k, ops); if (r) return r;
             if (k.rank == 0) {
@@ -703,7 +703,7 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         }
         return VP_OK;
     });
-    if (!rc) M->have_profile = true;
+    if (!rc && M->want_profile) { M->have_profile = true; M->need_plan = true; M->want_profile = false; }    // re-cut at the next bin
     return rc;
 }
 
@@ -789,7 +789,7 @@ VP_EXPORT int vp_rebalance(vp_ctx* c)
 {
     if (!c) return VP_ERR_BAD_ARG;
     if (!c->multi) return VP_OK;                               // a single-device context has nothing to cut
-    c->multi->need_plan = true;
+    c->multi->want_profile = true;     // the next vp_raymarch also records where its samples fall; the vp_bin after it re-cuts the slabs
     return VP_OK;
 }
 

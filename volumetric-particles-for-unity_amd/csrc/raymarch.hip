@@ -501,7 +501,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     float tin = 1.0f, aA = 0.f;
     const float cutoff = (PARTIAL && ho.t_in) ? VPFX_RM_HANDOFF_CUTOFF : k.alpha_cutoff;
     if (PARTIAL && ho.t_in) {
-        for (int j = 0; j < ho.n_in; ++j) tin *= ho.t_in[(size_t)j * ho.plane + pi];
+        int code = 0;                                          // product of the maps = sum of their codes (RmHandoff: t = 2^(-code / 8))
+        for (int j = 0; j < ho.n_in; ++j) code += ho.t_in[(size_t)j * ho.plane + pi];
+        tin = __builtin_amdgcn_exp2f(-0.125f * (float)code);
         if (early_out && tin <= cutoff) done = true;           // hidden by the slabs in front before this one starts
     }
 
@@ -627,7 +629,8 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         dst = d;
         if (PARTIAL) {
             if (!over && early_out && (1.0f - d.w) * tin <= cutoff) done = true;
-            if (ho.zsamples && nsamp != ns_start) atomicAdd(ho.zsamples + zz, (unsigned)(nsamp - ns_start));   // uniform address: one atomic per wave
+            if (ho.zsamples && nsamp != ns_start)               // uniform address: hipcc reduces over the wave, one atomic per wave and slice
+                atomicAdd(ho.zsamples + (blockIdx.x & (VPFX_ZPROF_COPIES - 1)) * k.Nz + zz, (unsigned)(nsamp - ns_start));
         } else if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
     }
 
@@ -638,9 +641,12 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         if (PARTIAL) img_under[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (PARTIAL && ho.t_out0) {
+        // code = floor(-8 log2 t), capped at 255: the decoded 2^(-code / 8) is never below t (a conservative bound: it can only make a
+        // ray behind march a little longer, never stop it early), within a factor 2^(1/8) of it down to 2^-31.9
+        auto encode = [](float t) { return (uint8_t)(int)fminf(-8.0f * __builtin_amdgcn_logf(t), 255.0f); };
         const float t0 = storedA ? 1.0f - aA : 1.0f - dst.w;
-        ho.t_out0[pi] = t0;
-        if (ho.t_out1) ho.t_out1[pi] = storedA ? t0 * (1.0f - dst.w) : t0;
+        ho.t_out0[pi] = encode(t0);
+        if (ho.t_out1) ho.t_out1[pi] = encode(storedA ? t0 * (1.0f - dst.w) : t0);
     }
     if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
 }

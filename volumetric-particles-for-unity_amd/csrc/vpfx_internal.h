@@ -71,17 +71,23 @@ struct RmConsts {
     float alpha_cutoff;           // early-out once (1 - dst.a) <= cutoff in the UNDER phase (0 = exact only)
 };
 
-// Cross-slab saturation hand-off of the ray-march (slab kernels only; raymarch.hip).  The reference's single render target sees every metavoxel (VPR.cs:652-711), so one
-// GPU stops a ray as soon as it is saturated; a slab on its own only knows its own metavoxels.  t_in = n maps [n][H][W] of the transmittance
-// (1 - alpha) of slabs that are composited IN FRONT of this one (received from the other GPUs); their product bounds what this slab can
-// still contribute, and a ray stops once (1 - dst.a) * prod(t_in) <= 2^-25 -- with no map that is exactly the single-GPU rule
+// Cross-slab saturation hand-off of the ray-march (slab kernels only; raymarch.hip).  The reference's single render target sees every
+// metavoxel (VPR.cs:652-711), so one GPU stops a ray as soon as it is saturated; a slab on its own only knows its own metavoxels.
+// A hand-off map is one BYTE per pixel: code = floor(-8 log2 t) (capped at 255) of a transmittance t = 1 - alpha, decoded as
+// 2^(-code / 8) >= t -- a conservative bound within a factor 2^(1/8) down to 2^-31.9; the product of maps is the sum of their codes.
+// (2 MB per map at 1080p instead of 8.3 MB as f32: the maps cross xGMI point to point between slab groups, on the critical path.)
+// t_in = n maps [n][H][W] of slabs that are composited IN FRONT of this one (received from the other GPUs); their product bounds what this
+// slab can still contribute, and a ray stops once (1 - dst.a) * prod(t_in) <= 2^-25 -- with no map that is exactly the single-GPU rule
 // 1 - dst.a == 0 (1 - a is a multiple of 2^-24 near a = 1), with maps it skips contributions of at most 3e-8.  t_out0 / t_out1 = this slab's
-// own transmittance for the slabs behind it: 1 - alpha(phase-A image) and (1 - alpha(A)) (1 - alpha(B)) (equal unless the slab straddles
-// zBoundary: phase-A slabs behind it are only hidden by its phase-A part).  zsamples[zz] += samples executed in light-axis slice zz (the work
-// profile the slab cut is balanced with).  All pointers nullable.
+// own maps for the slabs behind it: 1 - alpha(phase-A image) and (1 - alpha(A)) (1 - alpha(B)) (equal unless the slab straddles
+// zBoundary: phase-A slabs behind it are only hidden by its phase-A part).  zsamples[zz] += samples executed in light-axis slice zz (the
+// work profile the slab cut is balanced with).  All pointers nullable.
+#ifndef VPFX_ZPROF_COPIES
+#define VPFX_ZPROF_COPIES 64      // zsamples is [COPIES][Nz], one copy per workgroup index mod COPIES: every wave adds to ~12 slices, and ~30 000
+#endif                            // waves hammering the same 32 addresses would serialise in the L2's atomic units; readers sum the copies
 struct RmHandoff {
-    const float* t_in; int n_in; size_t plane;
-    float* t_out0; float* t_out1;
+    const uint8_t* t_in; int n_in; size_t plane;
+    uint8_t* t_out0; uint8_t* t_out1;
     unsigned* zsamples;
 };
 
@@ -101,6 +107,7 @@ struct vp_ctx {
     vp_config cfg{};
     vp_multi* multi = nullptr;    // non-null: a fan-out context (its slabs live in child contexts); every entry point forwards
     bool test_chain_timeout = false;
+    bool no_zprofile = false;     // VPFX_NO_ZPROFILE=1 in the environment at vp_create: measurement switch, slab ray-march without the per-slice sample profile
     int device = 0;
     hipStream_t stream = nullptr;
     GridConsts g{};
@@ -175,7 +182,7 @@ struct vp_ctx {
     float* d_image = nullptr;     // [H][W][4]
     float* d_scene_depth = nullptr;
     unsigned long long* d_samples = nullptr;
-    unsigned* d_zsamples = nullptr; // [Nz] samples executed per light-axis slice by the last slab ray-march (RmHandoff::zsamples)
+    unsigned* d_zsamples = nullptr; // [VPFX_ZPROF_COPIES][Nz] samples executed per light-axis slice by the last slab ray-march (RmHandoff::zsamples)
     int* d_brick_hit = nullptr;   // [brick_hit_cap] set to 1 by the ray-march when a brick contributes a sample
     size_t brick_hit_cap = 0;
     long long last_samples = 0;
@@ -238,6 +245,7 @@ int  launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend
 int    launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out, size_t npix);
 int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);
 // api.cpp: the single-device entry points the fan-out calls on its slab contexts
+int  api_read_zsamples(vp_ctx* c, long long* out /* [Nz] */, bool sync);   // sum of the copies; sync = wait for the stream first
 int  vp_create_single(const vp_config* cfg, vp_ctx** out);
 void vp_destroy_single(vp_ctx* c);
 int  api_stream_sync(vp_ctx* c);
