@@ -58,6 +58,22 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def cpu_quota_cores():
+    """CPU bandwidth limit of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None: 128 OpenMP threads on a 16-core quota
+    explain a poor parallel speed-up of the CPU leg better than anything in its code."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(sc, threads=0):
     """Time the CPU oracle (a port of the reference's algorithm; the reference itself is C# + HLSL and cannot run
     here) on the GPU box's host cores, compiled -march=native on that box.  Reported, not shipped: this is the only place bench.py
@@ -77,6 +93,7 @@ def cpu_baseline(sc, threads=0):
     out = {
         "value": units / (t3 - t0) / 1e6, "unit": "M(voxels+samples)/s", "cores": threads or o.L.vpo_max_threads(),
         "kind": "port", "build": "gcc -O3 -march=native -fopenmp, built on this box",
+        "cpus_visible": len(os.sched_getaffinity(0)), "cgroup_cpu_quota_cores": cpu_quota_cores(),
         "sample": f"one full step of {sc.name} (bin {t1 - t0:.3f}s, fill {t2 - t1:.3f}s, raymarch {t3 - t2:.3f}s)",
         "fill_mvoxels_per_s": st["voxels_filled"] / (t2 - t1) / 1e6,
         "raymarch_msamples_per_s": st["samples"] / (t3 - t2) / 1e6,
@@ -103,6 +120,9 @@ def cpu_baseline(sc, threads=0):
         "fill_mvoxels_per_s": fill_rate / 1e6, "raymarch_msamples_per_s": rm_rate / 1e6,
         "seconds_1thread_full_step_extrapolated": est, "value": units / est / 1e6,
         "parallel_speedup_of_the_port": est / (t3 - t0),
+        "note": ("a weak baseline: OpenMP over metavoxel columns (z serial, as in the reference) and pixel rows reaches only this speed-up over its own "
+                 "single thread on this box's host cores (SMT threads, shared host); reported for the record -- the roofline fraction, not the "
+                 "GPU/CPU ratio, says how good the kernels are"),
     }
     o1.close()
     return out

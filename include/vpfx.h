@@ -352,6 +352,39 @@ int  vp_z_histogram(vp_ctx* ctx, int64_t* pairs_per_z /* [Nz] */);
 /* zBoundary of RenderMetavoxels (VPR.cs:642-648) for this frame/camera. */
 int  vp_z_boundary(vp_ctx* ctx, const vp_camera* cam, int32_t* z_boundary);
 
+/* ---- Unity native-plugin hookup ----------------------------------------------------------------------------------
+ * The reference does its GPU work from OnPostRender on Unity's main thread through Graphics.* calls (VPR.cs:181-220).  A native plugin works
+ * on Unity's RENDER thread: the C# component fills a vp_unity_frame, calls GL.IssuePluginEvent(vp_unity_render_event_func(), slot), and the
+ * callback runs [vp_set_frame] -> [vp_bin -> vp_fill] -> vp_raymarch there, writing particlesRT into the output registered for the slot.
+ * UnityPluginLoad / UnityPluginUnload are the two names Unity's plugin loader looks up (IUnityInterface.h); the IUnityInterfaces* is kept
+ * opaque.  Pointers inside the frame (particles, cube map, depth maps) must stay valid until the event has run; the struct itself is copied. */
+#define VP_UNITY_MAX_SLOTS 8
+#define VP_UNITY_SET_FRAME    1   /* light / grid moved: UpdateMetavoxelPositions first                  VPR.cs:188-195 */
+#define VP_UNITY_BIN_AND_FILL 2   /* this frame re-bins and re-fills (Time.frameCount % updateInterval)  VPR.cs:186     */
+typedef struct vp_unity_frame {
+    vp_ctx* ctx;
+    int32_t flags;                        /* VP_UNITY_* */
+    int32_t particle_count;
+    float light_to_world[16];
+    float grid_center[3];
+    float psys_local_to_world[16];
+    const void* particles;                /* ParticleSystem.Particle[] (pinned), particle_count records */
+    vp_particle_layout layout;
+    vp_fill_params fill;
+    vp_camera camera;
+    vp_raymarch_params raymarch;
+} vp_unity_frame;
+typedef void (*vp_unity_render_event)(int event_id);
+void UnityPluginLoad(void* unity_interfaces);
+void UnityPluginUnload(void);
+vp_unity_render_event vp_unity_render_event_func(void);            /* pass to GL.IssuePluginEvent with eventId = slot */
+int  vp_unity_set_frame_desc(int32_t slot, const vp_unity_frame* frame);
+/* Where the event writes particlesRT ([H][W][4] f32 premultiplied): a HIP device pointer (written by the ray-march itself) and / or a host
+ * buffer (read back after it).  At least one must be non-NULL when the event runs. */
+int  vp_unity_register_output(int32_t slot, void* d_rgba_out, float* h_rgba_out);
+/* Status of the most recent event of the slot (Unity's callback returns void) and how many events have run. */
+int  vp_unity_last_status(int32_t slot, uint64_t* events_run);
+
 /* ---- parity probes / stats ------------------------------------------------------------------ */
 int  vp_get_mv_positions(vp_ctx* ctx, float* pos_out /* [Nz][Ny][Nx][3] */);
 int  vp_read_binlist(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz, int32_t* ids, int32_t cap, int32_t* n);

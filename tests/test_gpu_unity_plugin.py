@@ -1,0 +1,85 @@
+"""The Unity native-plugin entry points (include/vpfx.h "Unity native-plugin hookup", csrc/unity_plugin.cpp): UnityPluginLoad, a frame
+description per slot, and the render-event callback that Unity would invoke on its render thread via GL.IssuePluginEvent -- driven here from a
+second host thread.  The frame it produces must be the one the direct calls produce (VPR.cs:181-220: set-up, bin + fill every updateInterval
+frames, ray-march every frame)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from vpfx_amd import abi, engine as E, scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _desc(sc, eng, flags, particles):
+    f = abi.vp_unity_frame()
+    f.ctx = eng.h.value
+    f.flags = flags
+    f.particle_count = len(particles)
+    l2w = np.ascontiguousarray(sc.light_to_world, dtype=np.float32).reshape(-1)
+    p2w = np.ascontiguousarray(sc.psys_local_to_world, dtype=np.float32).reshape(-1)
+    for i in range(16):
+        f.light_to_world[i] = float(l2w[i]); f.psys_local_to_world[i] = float(p2w[i])
+    for i in range(3):
+        f.grid_center[i] = float(sc.grid_center[i])
+    f.particles = particles.ctypes.data
+    f.layout = sc.layout
+    f.fill = sc.fill_params()
+    f.camera = sc.camera()
+    f.raymarch = sc.raymarch_params()
+    return f
+
+
+def _issue_plugin_event(fn, slot):
+    """GL.IssuePluginEvent: Unity calls the function on its render thread, not on the thread that asked for it."""
+    t = threading.Thread(target=fn, args=(slot,))
+    t.start(); t.join()
+
+
+@pytest.mark.parametrize("fanout", [False, True])
+def test_render_event_runs_the_frame_on_another_thread(fanout):
+    L = E.lib()
+    L.vp_unity_render_event_func.restype = C.CFUNCTYPE(None, C.c_int)
+    sc = S.make_scene("C1", cubemap="r8")
+    direct = E.Engine(sc.config())
+    direct.set_frame(sc.light_to_world, sc.grid_center)
+    direct.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    direct.fill(sc.fill_params())
+    ref = direct.raymarch(sc.camera(), sc.raymarch_params())
+
+    eng = E.Engine(sc.config(devices=[0, 0], multi_flags=abi.VP_MULTI_PEER_COPY) if fanout else sc.config())
+    L.UnityPluginLoad(None)
+    fn = L.vp_unity_render_event_func()
+    slot = 3
+    ev = C.c_uint64(0)
+    assert L.vp_unity_last_status(slot, C.byref(ev)) == abi.VP_ERR_STATE and ev.value == 0          # nothing has run yet
+    _issue_plugin_event(fn, slot)                                                                    # no description: an error, not a crash
+    assert L.vp_unity_last_status(slot, None) == abi.VP_ERR_STATE
+    particles = np.ascontiguousarray(sc.particles)
+    frame = _desc(sc, eng, abi.VP_UNITY_SET_FRAME | abi.VP_UNITY_BIN_AND_FILL, particles)
+    assert L.vp_unity_set_frame_desc(slot, C.byref(frame)) == 0
+    _issue_plugin_event(fn, slot)
+    assert L.vp_unity_last_status(slot, None) == abi.VP_ERR_STATE                                    # no output registered
+    host = np.zeros((sc.height, sc.width, 4), dtype=np.float32)
+    dev = torch.zeros((sc.height, sc.width, 4), device="cuda")
+    assert L.vp_unity_register_output(slot, C.c_void_p(dev.data_ptr()), host.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    _issue_plugin_event(fn, slot)
+    assert L.vp_unity_last_status(slot, C.byref(ev)) == 0 and ev.value == 3, E.lib().vp_last_error(eng.h)
+    tol = 2e-5 if fanout else 0.0
+    assert np.abs(host - ref).max() <= tol and np.abs(dev.cpu().numpy() - ref).max() <= tol
+    # a frame between two fills (updateInterval): ray-march only, other camera, host output only
+    sc.set_camera((6.0, 3.0, -14.0))
+    ref2 = direct.raymarch(sc.camera(), sc.raymarch_params())
+    frame2 = _desc(sc, eng, 0, particles)
+    assert L.vp_unity_set_frame_desc(slot, C.byref(frame2)) == 0
+    assert L.vp_unity_register_output(slot, None, host.ctypes.data_as(C.POINTER(C.c_float))) == 0
+    _issue_plugin_event(fn, slot)
+    assert L.vp_unity_last_status(slot, None) == 0
+    assert np.abs(host - ref2).max() <= tol
+    assert L.vp_unity_set_frame_desc(99, C.byref(frame2)) == abi.VP_ERR_BAD_ARG
+    L.UnityPluginUnload()
+    assert L.vp_unity_last_status(slot, C.byref(ev)) == abi.VP_ERR_STATE and ev.value == 0          # unloading forgets every slot
+    eng.close(); direct.close()

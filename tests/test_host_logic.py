@@ -123,3 +123,50 @@ def test_slice_costs_weigh_near_metavoxels_more():
     pos[..., 2] = np.arange(4)[:, None, None] * 3.0 + 10.0                   # slices at distance 10, 13, 16, 19 from a camera at the origin
     w, f, r = PAR.slice_costs(cnt, pos, (0, 0, 0), 3.0, 1080, np.radians(60.0), 64)
     assert f[0] == f[3] and r[0] > r[1] > r[2] > r[3] and abs(r[0] / r[3] - (19.0 / 10.0) ** 2) < 0.05
+
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+
+
+# ---- multi-GPU host logic of the library (csrc/host_logic.cpp: hl_plan_slabs, hl_blend_plan), no GPU needed
+def test_library_slab_planner_is_valid_and_optimal():
+    import itertools
+    from vpfx_amd import engine as E
+    rng = np.random.default_rng(7)
+    assert E.plan_slabs(32, 4) == [(0, 8), (8, 16), (16, 24), (24, 32)]                # no costs: uniform
+    assert E.plan_slabs(5, 5) == [(i, i + 1) for i in range(5)]
+    with pytest.raises(E.VpfxError):
+        E.plan_slabs(4, 5)                                                             # at most one rank per slice
+    for trial in range(120):
+        nz = int(rng.integers(3, 10)); world = int(rng.integers(2, min(nz, 5) + 1))
+        kind = trial % 3
+        F = rng.random(nz) * 3 if kind else np.eye(nz)[int(rng.integers(nz))] * 5       # random / one-hot histograms
+        R = rng.random(nz) * 2 if kind != 2 else np.concatenate([rng.random(2) * 9, np.zeros(nz - 2)])   # ray-march work piled at the front
+        b = E.plan_slabs(nz, world, F, R, 1)
+        assert b[0][0] == 0 and b[-1][1] == nz and all(b0 < b1 for b0, b1 in b) and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        obj = lambda bb: 1.3 * max(F[a:c].sum() for a, c in bb) + max(R[a:c].sum() for a, c in bb)
+        best = min(obj(list(zip((0,) + c, c + (nz,)))) for c in itertools.combinations(range(1, nz), world - 1))
+        assert abs(obj(b) - best) <= 1e-9                                              # exact optimum of the two-stage frame model
+        # with hand-off groups the cut stays valid and is never worse than the fill-only cut under that model
+        g = E.plan_slabs(nz, world, F, R, 2)
+        assert g[0][0] == 0 and g[-1][1] == nz and all(b0 < b1 for b0, b1 in g)
+
+
+def test_library_blend_plan_matches_the_python_pipeline_and_orders_front_to_back():
+    from vpfx_amd import engine as E, parallel as PAR
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        nz = int(rng.integers(2, 20)); world = int(rng.integers(1, min(nz, 8) + 1))
+        cuts = [0] + sorted(rng.choice(np.arange(1, nz), size=world - 1, replace=False).tolist()) + [nz]
+        bounds = list(zip(cuts, cuts[1:]))
+        zb = int(rng.integers(-1, nz))
+        chain, plan, strad = E.blend_plan(bounds, zb)
+        ref_plan, ref_strad = PAR.blend_plan(bounds, zb)
+        assert strad == ref_strad
+        assert [(r, 1 if (which == "under" and r == ref_strad) else 0, k) for r, which, k in ref_plan] == plan
+        assert sorted(chain) == list(range(world))
+        # front to back: the straddler first, then phase-A-only slabs with zz descending, then phase-B-only slabs with zz ascending
+        a_only = [r for r in range(world) if bounds[r][1] - 1 <= zb]
+        b_only = [r for r in range(world) if bounds[r][0] > zb]
+        assert chain == ([strad] if strad is not None else []) + sorted(a_only, reverse=True) + sorted(b_only)

@@ -101,6 +101,10 @@ class vp_multi_info(C.Structure):
     ]
 
 
+VP_UNITY_MAX_SLOTS = 8
+VP_UNITY_SET_FRAME, VP_UNITY_BIN_AND_FILL = 1, 2
+
+
 class vp_particle_layout(C.Structure):
     _fields_ = [
         ("stride", C.c_int32),
@@ -172,6 +176,22 @@ class vp_stats(C.Structure):
     ]
 
 
+class vp_unity_frame(C.Structure):
+    _fields_ = [
+        ("ctx", C.c_void_p),
+        ("flags", C.c_int32),
+        ("particle_count", C.c_int32),
+        ("light_to_world", C.c_float * 16),
+        ("grid_center", C.c_float * 3),
+        ("psys_local_to_world", C.c_float * 16),
+        ("particles", C.c_void_p),
+        ("layout", vp_particle_layout),
+        ("fill", vp_fill_params),
+        ("camera", vp_camera),
+        ("raymarch", vp_raymarch_params),
+    ]
+
+
 # every symbol include/vpfx.h declares (checked by tests/test_abi.py against the built library)
 EXPORTED_SYMBOLS = [
     "vp_create", "vp_destroy", "vp_last_error", "vp_abi_version", "vp_set_stream", "vp_sync", "vp_pin_host_buffer", "vp_unpin_host_buffer",
@@ -184,4 +204,6 @@ EXPORTED_SYMBOLS = [
     "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",
     "vp_raymarch_partial_handoff_device", "vp_read_zsamples",
     "vp_get_multi_info", "vp_rebalance", "vp_rccl_unique_id", "vp_plan_slabs", "vp_blend_plan",
+    "vp_unity_render_event_func", "vp_unity_set_frame_desc", "vp_unity_register_output", "vp_unity_last_status",
 ]
+UNITY_LOADER_SYMBOLS = ["UnityPluginLoad", "UnityPluginUnload"]        # the two names Unity's plugin loader looks up

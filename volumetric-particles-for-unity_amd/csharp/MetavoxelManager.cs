@@ -38,6 +38,11 @@ namespace MetavoxelEngine
         public bool fadeOutParticles = false;
         public float opacityFactor = 0.04f;
         public int softParticleStepDistance = 20;
+        // ---- added by this binding ---------------------------------------------------------------------------
+        public int[] gpuDevices = new int[0];      // HIP ordinals; empty / one entry = one GPU.  N entries: the library cuts the grid into N
+                                                   // light-axis slabs, one per GPU, with RCCL inside (vp_config.num_devices / devices[])
+        public int rebalanceInterval = 240;        // multi-GPU: frames between vp_rebalance calls (0 = never re-cut the slabs)
+        public bool useRenderThread = false;       // run the frame from Unity's render thread (GL.IssuePluginEvent) instead of OnPostRender
 
         // ---- C ABI (include/vpfx.h) ---------------------------------------------------------------------
         [StructLayout(LayoutKind.Sequential)]
@@ -46,6 +51,11 @@ namespace MetavoxelEngine
             public int nx, ny, nz, num_voxels, num_border; public float mv_scale;
             public int width, height, device, slab_z0, slab_z1, exact_math, no_early_out;
             [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public int[] reserved;
+            // ABI 3: multi-GPU fan-out inside the library
+            public int num_devices;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 8)] public int[] devices;
+            public int world_size, first_rank, multi_flags, rm_groups;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 128)] public byte[] rccl_unique_id;
         }
         [StructLayout(LayoutKind.Sequential)]
         struct vp_particle_layout
@@ -75,6 +85,17 @@ namespace MetavoxelEngine
             [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public int[] reserved;
         }
 
+        [StructLayout(LayoutKind.Sequential)]
+        struct vp_unity_frame                  // one frame for the render-thread callback (include/vpfx.h "Unity native-plugin hookup")
+        {
+            public IntPtr ctx; public int flags, particle_count;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] light_to_world;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public float[] grid_center;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 16)] public float[] psys_local_to_world;
+            public IntPtr particles;
+            public vp_particle_layout layout; public vp_fill_params fill; public vp_camera camera; public vp_raymarch_params raymarch;
+        }
+
         const string LIB = "vpfx";
         [DllImport(LIB)] static extern int vp_create(ref vp_config cfg, out IntPtr ctx);
         [DllImport(LIB)] static extern void vp_destroy(IntPtr ctx);
@@ -91,6 +112,11 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_read_particles_rt(IntPtr ctx, IntPtr rgbaOut);
         [DllImport(LIB)] static extern int vp_pin_host_buffer(IntPtr ctx, IntPtr ptr, ulong bytes);
         [DllImport(LIB)] static extern int vp_unpin_host_buffer(IntPtr ctx, IntPtr ptr);
+        [DllImport(LIB)] static extern int vp_rebalance(IntPtr ctx);
+        [DllImport(LIB)] static extern IntPtr vp_unity_render_event_func();
+        [DllImport(LIB)] static extern int vp_unity_set_frame_desc(int slot, ref vp_unity_frame frame);
+        [DllImport(LIB)] static extern int vp_unity_register_output(int slot, IntPtr dRgbaOut, IntPtr hRgbaOut);
+        [DllImport(LIB)] static extern int vp_unity_last_status(int slot, out ulong eventsRun);
 
         IntPtr ctx = IntPtr.Zero;
         ParticleSystem.Particle[] parts;
@@ -124,7 +150,11 @@ namespace MetavoxelEngine
             var cfg = new vp_config {
                 nx = numMetavoxelsX, ny = numMetavoxelsY, nz = numMetavoxelsZ, num_voxels = numVoxelsInMetavoxel,
                 num_border = numBorderVoxels, mv_scale = mvScale.x, width = Screen.width, height = Screen.height,
-                device = -1, slab_z0 = 0, slab_z1 = 0, exact_math = 0, no_early_out = 0, reserved = new int[3] };
+                device = -1, slab_z0 = 0, slab_z1 = 0, exact_math = 0, no_early_out = 0, reserved = new int[3],
+                num_devices = gpuDevices.Length > 1 ? gpuDevices.Length : 0, devices = new int[8], world_size = 0, first_rank = 0,
+                multi_flags = 0, rm_groups = 0, rccl_unique_id = new byte[128] };
+            if (gpuDevices.Length == 1) cfg.device = gpuDevices[0];
+            for (int i = 0; i < gpuDevices.Length && i < 8; i++) cfg.devices[i] = gpuDevices[i];    // the ONE thing a multi-GPU host adds
             int rc = vp_create(ref cfg, out ctx);
             if (rc != 0) { Debug.LogError("vp_create failed (" + rc + "): " + Marshal.PtrToStringAnsi(vp_last_error(IntPtr.Zero))); return; }
             parts = new ParticleSystem.Particle[particleSys.maxParticles];
@@ -133,6 +163,7 @@ namespace MetavoxelEngine
             rgbaHandle = GCHandle.Alloc(rgba, GCHandleType.Pinned);
             vp_pin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject(), (ulong)rgba.Length * 4);   // speed hint only: failure is harmless
             particlesTex = new Texture2D(Screen.width, Screen.height, TextureFormat.RGBAFloat, false);
+            if (useRenderThread) vp_unity_register_output(0, IntPtr.Zero, rgbaHandle.AddrOfPinnedObject());   // slot 0: particlesRT read back to `rgba`
             int S = displacementTexture.width;
             cubemapR = new byte[6 * S * S];
             CubemapFace[] faces = { CubemapFace.PositiveX, CubemapFace.NegativeX, CubemapFace.PositiveY,
@@ -151,12 +182,16 @@ namespace MetavoxelEngine
         {
             if (ctx == IntPtr.Zero) return;
             if (rgbaHandle.IsAllocated) { vp_unpin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject()); rgbaHandle.Free(); }
+            if (partsHandle.IsAllocated) partsHandle.Free();
+            if (cubeHandle.IsAllocated) cubeHandle.Free();
             vp_destroy(ctx); ctx = IntPtr.Zero;
         }
 
         void OnPostRender()                                                // VPR.cs:181-220
         {
             if (ctx == IntPtr.Zero) return;
+            if (gpuDevices.Length > 1 && rebalanceInterval > 0 && Time.frameCount % rebalanceInterval == 0) vp_rebalance(ctx);
+            if (useRenderThread) { IssueFrameOnRenderThread(); return; }
             // the very first call always bins + fills: ray-marching before any fill is VP_ERR_STATE
             if (Time.frameCount % updateInterval == 0 || !filledOnce)
             {
@@ -174,6 +209,32 @@ namespace MetavoxelEngine
             // CompositeParticles.shader: Blend One OneMinusSrcAlpha, One One).
         }
 
+        // The same frame from Unity's render thread: describe it, GL.IssuePluginEvent, pick the result up next frame (the callback runs
+        // [vp_set_frame] -> [vp_bin -> vp_fill] -> vp_raymarch and writes `rgba`; vp_unity_last_status reports how it went).
+        GCHandle partsHandle, cubeHandle;
+        void IssueFrameOnRenderThread()
+        {
+            ulong done; int last = vp_unity_last_status(0, out done);
+            if (done > 0) { Check(last, "render-thread frame"); if (last == 0) { filledOnce = true; cubemapResident = true; particlesTex.SetPixelData(rgba, 0); particlesTex.Apply(false); } }
+            bool refill = Time.frameCount % updateInterval == 0 || !filledOnce;
+            bool moved = dirLight.transform.rotation != lightOrientation || wsGridCenter != gridCenter.transform.position || !filledOnce;
+            if (moved) { lightOrientation = dirLight.transform.rotation; wsGridCenter = gridCenter.transform.position; }
+            vp_camera cam; vp_raymarch_params rp;
+            CameraAndParams(out cam, out rp);
+            int n = refill ? particleSys.GetParticles(parts) : 0;
+            if (!partsHandle.IsAllocated) partsHandle = GCHandle.Alloc(parts, GCHandleType.Pinned);    // stays pinned: the event reads it later
+            if (!cubeHandle.IsAllocated) cubeHandle = GCHandle.Alloc(cubemapR, GCHandleType.Pinned);
+            var fill = FillParams();
+            if (!cubemapResident) fill.cubemap = cubeHandle.AddrOfPinnedObject();
+            Vector3 g = wsGridCenter;
+            var frame = new vp_unity_frame {
+                ctx = ctx, flags = (moved ? 1 : 0) | (refill ? 2 : 0), particle_count = n,
+                light_to_world = ToArray(dirLight.transform.localToWorldMatrix), grid_center = new float[] { g.x, g.y, g.z },
+                psys_local_to_world = ToArray(particleSys.transform.localToWorldMatrix), particles = partsHandle.AddrOfPinnedObject(),
+                layout = ParticleLayout(), fill = fill, camera = cam, raymarch = rp };
+            if (Check(vp_unity_set_frame_desc(0, ref frame), "vp_unity_set_frame_desc")) GL.IssuePluginEvent(vp_unity_render_event_func(), 0);
+        }
+
         void UpdateMetavoxelPositions()                                    // VPR.cs:370-394
         {
             Vector3 g = wsGridCenter;
@@ -183,8 +244,16 @@ namespace MetavoxelEngine
         void BinParticlesToMetavoxels()                                    // VPR.cs:397-457
         {
             int n = particleSys.GetParticles(parts);
+            var lay = ParticleLayout();
+            GCHandle h = GCHandle.Alloc(parts, GCHandleType.Pinned);       // zero-copy view; the library keeps no pointer
+            try { Check(vp_bin(ctx, h.AddrOfPinnedObject(), n, ref lay, ToArray(particleSys.transform.localToWorldMatrix)), "vp_bin"); }
+            finally { h.Free(); }
+        }
+
+        vp_particle_layout ParticleLayout()
+        {
             // explicit field offsets: the managed layout of ParticleSystem.Particle is Unity-version specific
-            var lay = new vp_particle_layout {
+            return new vp_particle_layout {
                 stride = Marshal.SizeOf(typeof(ParticleSystem.Particle)),
                 off_position = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Position"),
                 off_size = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Size"),
@@ -192,9 +261,6 @@ namespace MetavoxelEngine
                 off_lifetime = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_Lifetime"),
                 off_start_lifetime = (int)Marshal.OffsetOf(typeof(ParticleSystem.Particle), "m_StartLifetime"),
                 rotation_in_radians = 1 /* the raw field is radians; the .rotation property converts to degrees */ };
-            GCHandle h = GCHandle.Alloc(parts, GCHandleType.Pinned);       // zero-copy view; the library keeps no pointer
-            try { Check(vp_bin(ctx, h.AddrOfPinnedObject(), n, ref lay, ToArray(particleSys.transform.localToWorldMatrix)), "vp_bin"); }
-            finally { h.Free(); }
         }
 
         vp_fill_params FillParams()                                        // SetFillPassConstants VPR.cs:523-554

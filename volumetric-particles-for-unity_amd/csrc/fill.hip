@@ -201,10 +201,16 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
         // give the face centre like the EXACT branch), one FMA per axis
         const float invS = Sf * __builtin_amdgcn_rcpf(ma2 + 1.0e-30f);     // + 1e-30: bit-neutral for any real direction, keeps 1/0 finite
         fx = fmaf(sc, invS, f.half_s_m05); fy = fmaf(tc, invS, f.half_s_m05);
-        if (DONE) {
+#ifndef VPFX_DONE_ALWAYS_EXACT
+#define VPFX_DONE_ALWAYS_EXACT 0
+#endif
+#ifndef VPFX_DONE_SKIP_EXACT
+#define VPFX_DONE_SKIP_EXACT 0
+#endif
+        if (DONE && !VPFX_DONE_SKIP_EXACT) {
             const float wx = fx - floorf(fx), wy = fy - floorf(fy);
             const bool near_int = fminf(wx, wy) < 1.0e-4f || fmaxf(wx, wy) > 1.0f - 1.0e-4f;
-            if (__builtin_amdgcn_ballot_w64(near_int)) {                   // wave-uniform, rare
+            if (VPFX_DONE_ALWAYS_EXACT || __builtin_amdgcn_ballot_w64(near_int)) {   // wave-uniform, rare
                 float uh = 0.f, vh = 0.f;
                 if (ma2 > 0.f) { const float inv = 1.0f / ma2; uh = sc * inv; vh = tc * inv; }
                 fx = fmaf(uh, Sf, f.half_s_m05); fy = fmaf(vh, Sf, f.half_s_m05);
@@ -255,7 +261,11 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
         // (the saturate rides on the producing instruction's clamp bit; hipcc otherwise spends a v_max_f32 ... clamp after a literal-form FMA)
         if (DONE) {
             const float num = fmaf(d2, 4.0f, -net), rden = __builtin_amdgcn_rcpf(fmaf(net, 0.7f, -net));
-            asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(t) : "v"(num), "v"(rden));
+            // s_nop 0: rden comes straight out of v_rcp_f32, and on gfx950 a non-transcendental VALU that reads a transcendental's result
+            // needs one wait state in between.  hipcc inserts it for its own instructions but does not look inside inline asm: without it
+            // the multiply read a stale register whenever the scheduler placed it right behind the v_rcp (NV = 16 / 64 instantiations:
+            // thousands of wrong voxels, found by the randomised sweep).
+            asm("s_nop 0\n\tv_mul_f32_e64 %0, %1, %2 clamp" : "=v"(t) : "v"(num), "v"(rden));
         } else {
             const float q = d2 * __builtin_amdgcn_rcpf(net);
             asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(q), "s"(-13.333333f), "v"(smooth_c1));

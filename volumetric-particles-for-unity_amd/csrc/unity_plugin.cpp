@@ -1,0 +1,114 @@
+// unity_plugin.cpp -- the Unity low-level native-plugin hookup of the component that replaces VolumetricParticleRenderer
+// (SURVEY 8(f) row 3).  The reference issues its fill / ray-march as Graphics.Blit / DrawMeshNow from OnPostRender on the main thread
+// (VPR.cs:181-220); a native plugin does its GPU work on Unity's RENDER thread instead: C# fills a frame description, calls
+// GL.IssuePluginEvent(vp_unity_render_event_func(), slot), and Unity invokes the callback on the render thread, where the frame runs
+//     [vp_set_frame] -> [vp_bin -> vp_fill] -> vp_raymarch  (bin + fill only when the description says so: updateInterval, VPR.cs:186)
+// and the premultiplied RGBA lands in the output the host registered for the slot: a HIP device pointer (vp_raymarch_device writes it; how
+// the host obtains one for its render texture -- e.g. hipImportExternalMemory over the texture's exported allocation -- is its business)
+// and / or a host buffer.  The status of the last event is polled with vp_unity_last_status (Unity's callback returns void).
+// The entry points follow the shape of Unity's public plugin API (IUnityInterface.h: UnityPluginLoad / UnityPluginUnload exported by
+// name, a `void (*)(int eventId)` rendering event); Unity's own headers are not needed and not used: IUnityInterfaces* is kept as an
+// opaque pointer.  Nothing here is Unity-specific beyond that calling convention, so the tests drive it from a second host thread.
+#include <cstring>
+#include <mutex>
+
+#include "vpfx_internal.h"
+
+namespace {
+
+struct Slot {
+    vp_unity_frame frame{};
+    bool have_frame = false;
+    void* d_out = nullptr;
+    float* h_out = nullptr;
+    int status = VP_ERR_STATE;
+    unsigned long long events = 0;
+};
+std::mutex g_m;
+Slot g_slots[VP_UNITY_MAX_SLOTS];
+void* g_unity_interfaces = nullptr;
+bool g_loaded = false;
+
+void on_render_event(int slot)
+{
+    if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS) return;
+    vp_unity_frame f;
+    void* d_out;
+    float* h_out;
+    {
+        std::lock_guard<std::mutex> lk(g_m);
+        if (!g_slots[slot].have_frame) { g_slots[slot].status = VP_ERR_STATE; ++g_slots[slot].events; return; }
+        f = g_slots[slot].frame; d_out = g_slots[slot].d_out; h_out = g_slots[slot].h_out;
+    }
+    int rc = VP_OK;
+    vp_ctx* c = f.ctx;
+    if (!c) rc = VP_ERR_BAD_ARG;
+    if (!rc && (f.flags & VP_UNITY_SET_FRAME)) rc = vp_set_frame(c, f.light_to_world, f.grid_center);               // VPR.cs:188-195
+    if (!rc && (f.flags & VP_UNITY_BIN_AND_FILL)) {                                                                   // VPR.cs:186-201
+        rc = vp_bin(c, f.particles, f.particle_count, &f.layout, f.psys_local_to_world);
+        if (!rc) rc = vp_fill(c, &f.fill);
+    }
+    if (!rc) {                                                                                                        // VPR.cs:207
+        if (d_out) rc = vp_raymarch_device(c, &f.camera, &f.raymarch, d_out);
+        if (!rc && h_out) rc = d_out ? vp_read_last_image(c, d_out, h_out) : vp_raymarch(c, &f.camera, &f.raymarch, h_out);
+        if (!rc && !d_out && !h_out) rc = VP_ERR_STATE;                  // nowhere to put the frame: vp_unity_register_output first
+    }
+    std::lock_guard<std::mutex> lk(g_m);
+    g_slots[slot].status = rc;
+    ++g_slots[slot].events;
+}
+
+}  // namespace
+
+// read an image the ray-march left on the device back to the host (the host-buffer half of a slot that has both outputs)
+int vp_read_last_image(vp_ctx* c, const void* d_img, float* h_out)
+{
+    if (c->multi) c = multi_owner_of_slice(c, -1);
+    if (!c) return VP_ERR_STATE;
+    VP_HIP(hipSetDevice(c->device));
+    VP_HIP(hipMemcpyAsync(h_out, d_img, (size_t)c->cfg.width * c->cfg.height * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return api_stream_sync(c);
+}
+
+VP_EXPORT void UnityPluginLoad(void* unity_interfaces)
+{
+    std::lock_guard<std::mutex> lk(g_m);
+    g_unity_interfaces = unity_interfaces;
+    g_loaded = true;
+}
+
+VP_EXPORT void UnityPluginUnload(void)
+{
+    std::lock_guard<std::mutex> lk(g_m);
+    for (Slot& s : g_slots) s = Slot{};
+    g_unity_interfaces = nullptr;
+    g_loaded = false;
+}
+
+VP_EXPORT vp_unity_render_event vp_unity_render_event_func(void) { return on_render_event; }
+
+VP_EXPORT int vp_unity_set_frame_desc(int32_t slot, const vp_unity_frame* frame)
+{
+    if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS || !frame || !frame->ctx) return VP_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_m);
+    g_slots[slot].frame = *frame;          // copied: the caller's struct need not outlive the call (the arrays it points to must live until the event has run)
+    g_slots[slot].have_frame = true;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_unity_register_output(int32_t slot, void* d_rgba_out, float* h_rgba_out)
+{
+    if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS) return VP_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_m);
+    g_slots[slot].d_out = d_rgba_out;
+    g_slots[slot].h_out = h_rgba_out;
+    return VP_OK;
+}
+
+VP_EXPORT int vp_unity_last_status(int32_t slot, uint64_t* events_run)
+{
+    if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS) return VP_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_m);
+    if (events_run) *events_run = g_slots[slot].events;
+    return g_slots[slot].status;
+}

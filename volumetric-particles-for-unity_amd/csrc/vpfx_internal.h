@@ -269,6 +269,8 @@ int  multi_last_kernel_ms(vp_ctx* c, int stage, float* ms);
 int  multi_read_bincounts(vp_ctx* c, int32_t* counts);
 int  multi_read_lightmap(vp_ctx* c, float* out);
 vp_ctx* multi_owner_of_slice(vp_ctx* c, int zz);       // local child owning light-axis slice zz, or nullptr
+// unity_plugin.cpp
+int  vp_read_last_image(vp_ctx* c, const void* d_img, float* h_out);
 // occluders.hip
 int  launch_light_depth(vp_ctx* c, float nearz, float farz, float cam_dist, float* d_out);
 int  launch_scene_depth(vp_ctx* c, const vp_camera* cam, float* d_out);
