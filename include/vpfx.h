@@ -162,6 +162,10 @@ typedef struct vp_raymarch_params {
                                      submission order (DrawOrderColoring, RM.shader:123-138, 170-173; _OrderIndex = mvCount of
                                      VPR.cs:650-706, _NumMetavoxelsCovered VPR.cs:755).  Whole-grid contexts only               */
 
+#define VP_RM_SHOW_RAY_SAMPLES 16  /* perf view (not in the reference): every pixel = the number of lattice samples its ray executed, as
+                                     (n, n, n, 1) f32 -- the samples-per-ray heat map of SURVEY 8(f) row 4.  Unlike the reference's debug
+                                     views it leaves the saturation early-out on: it shows the work the frame really did */
+
 /* An opaque occluder: oriented box (the demo scene's ground/back planes and cubes are boxes).  Used to PRODUCE the two
  * scene-occlusion inputs of the path on the GPU instead of reading them back from Unity render targets:
  *   light depth map  <- lightCamera.RenderWithShader(GenerateLightDepthMap)   VPR.cs:184, 320-367, LDM.shader:6 (Cull Front:

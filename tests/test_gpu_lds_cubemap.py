@@ -110,3 +110,20 @@ def test_config3_r8_benchmark_workload_against_the_oracle():
     assert o.stats()["samples"] == g.stats()["samples"]
     cnt = o.bin_counts()
     assert brick_ulp_diff(o, g, cnt, step=211) <= 1
+    # EVERY brick of one whole light-axis layer (the densest one), not a sample of the grid: <= 1 fp16 ulp
+    zmid = int(np.argmax(cnt.reshape(cnt.shape[0], -1).sum(axis=1)))
+    layer = np.zeros_like(cnt)
+    layer[zmid] = cnt[zmid]
+    assert int((layer != 0).sum()) > 300
+    assert brick_ulp_diff(o, g, layer, step=1) <= 1
+    # ... and the benchmark's own ray-march -- the DEFAULT saturation early-out -- per pixel against the same oracle frame:
+    # it skips exact no-ops only, so the image is the oracle's and the samples are a subset
+    ge = E.Engine(sc.config())
+    ge.set_frame(sc.light_to_world, sc.grid_center)
+    ge.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    ge.fill(sc.fill_params())
+    ie = ge.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ie).max() <= 1e-3 and np.abs(ig - ie).max() <= 2e-6
+    se = ge.stats()
+    assert se["samples"] < 0.6 * o.stats()["samples"] and se["brick_format"] == 1 and se["bricks_sampled"] < se["occupied_mv"]
+    ge.close()

@@ -48,6 +48,10 @@ VPFX_MIX_FMA(mix_fma_lo, 0)
 VPFX_MIX_FMA(mix_fma_hi, 1)
 
 
+#ifndef VPFX_RM_CELLINFO
+#define VPFX_RM_CELLINFO 1      // per-cell (translation, brick slot) records for the streaming cell walk (see k_raymarch): 0.967 -> 0.951 ms at C3; 0 = A/B
+#endif
+
 // Explicitly issued 16-byte loads for the two-samples-per-iteration loop: the compiler otherwise sinks the second
 // sample's loads below the first sample's filter (four loads in flight instead of eight).  The asynchronous register
 // write is invisible to the compiler, so wait_quad() takes the destinations as in/out operands: every use is ordered
@@ -324,7 +328,8 @@ __device__ __forceinline__ F4 draw_order_color(int order_index, int num_covered)
 // Translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld for every occupied MV
 // (VPR.cs:774-778), same operation order as the matrix product the reference does per draw.
 __global__ void __launch_bounds__(256)
-k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict__ mvPos, int n, float4* __restrict__ out)
+k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict__ mvPos, int n, float4* __restrict__ out,
+           float4* __restrict__ cellinfo /* nullable: [N^3] records (translation, brick slot), preset to -1 */)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -338,6 +343,7 @@ k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict
         tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + c * k.c2w_t[2]) + t * k.c2w_t[3];
     }
     out[i] = make_float4(tr[0], tr[1], tr[2], 0.f);
+    if (cellinfo) cellinfo[mi] = make_float4(tr[0], tr[1], tr[2], __int_as_float(i));
 }
 
 // Dispatch order of the screen super-tiles (64x32 px): most expensive first, so that the long rays are not what the
@@ -441,7 +447,7 @@ __global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out,
-           RmHandoff ho)
+           RmHandoff ho, const float4* __restrict__ cellinfo)
 {
     const int lane = threadIdx.x;
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
@@ -574,11 +580,28 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         bool wfin = false;
         for (;;) {
             int best_r = over ? -1 : 0x7fffffff, best_cell = -1;
+#if VPFX_RM_CELLINFO
+            float4 ci = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+#endif
             if (stream) {
                 // next occupied cell along the ray
                 while (!wfin && walked < max_cells) {
                     const int cell = walk_step(wcx, wcy, wfin);
                     ++walked;
+#if VPFX_RM_CELLINFO
+                    // one 16-byte record per cell = (translation of _CameraToMetavoxel, brick slot or -1): occupancy, slot and translation
+                    // arrive with ONE load instead of three dependent ones (occupancy -> translation; the rank load runs beside it)
+                    if (!FLAGS && cell >= 0) {
+                        const float4 q4 = cellinfo[zz * nxy + cell];
+                        const int r = rank[cell];
+                        if (__float_as_int(q4.w) >= 0) {
+                            if (r > last) { best_r = r; best_cell = cell; ci = q4; }
+                            else { d = d_start; nsamp = ns_start; stream = false; last = -1; }
+                            break;
+                        }
+                        continue;
+                    }
+#endif
                     if (cell >= 0 && occ[cell] >= 0) {
                         const int r = rank[cell];
                         if (r > last) { best_r = r; best_cell = cell; }
@@ -603,11 +626,18 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             }
             if (best_cell < 0) break;
             last = best_r;
+#if VPFX_RM_CELLINFO
+            const bool have_ci = !FLAGS && stream;
+            const int bi = have_ci ? __float_as_int(ci.w) : occ[best_cell];
+            const float4 trv = have_ci ? ci : mvtrans[bi];
+#else
             const int bi = occ[best_cell];
+            const float4 trv = mvtrans[bi];
+#endif
             F4 src;
             const int ns0 = nsamp;
             const uint2* brick = bricks + (size_t)bi * NV * NV * NV;
-            if (!march_mv<NV, WRAP, FLAGS, GREY>(k, R, brick, mvtrans[bi], src, nsamp)) continue;
+            if (!march_mv<NV, WRAP, FLAGS, GREY>(k, R, brick, trv, src, nsamp)) continue;
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
                 src = phaseA ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
@@ -634,6 +664,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         } else if (!over && early_out && 1.0f - d.w <= k.alpha_cutoff) done = true;
     }
 
+    if (FLAGS && (k.flags & VP_RM_SHOW_RAY_SAMPLES)) dst = F4{(float)nsamp, (float)nsamp, (float)nsamp, 1.0f};   // perf view: samples per ray
     if (PARTIAL && storedA) {
         img_under[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
     } else {
@@ -643,6 +674,330 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     if (PARTIAL && ho.t_out0) {
         // code = floor(-8 log2 t), capped at 255: the decoded 2^(-code / 8) is never below t (a conservative bound: it can only make a
         // ray behind march a little longer, never stop it early), within a factor 2^(1/8) of it down to 2^-31.9
+        auto encode = [](float t) { return (uint8_t)(int)fminf(-8.0f * __builtin_amdgcn_logf(t), 255.0f); };
+        const float t0 = storedA ? 1.0f - aA : 1.0f - dst.w;
+        ho.t_out0[pi] = encode(t0);
+        if (ho.t_out1) ho.t_out1[pi] = encode(storedA ? t0 * (1.0f - dst.w) : t0);
+    }
+    if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_raymarch_flat: the same ray-march with a WAVE-COHERENT traversal (whole-grid or slab contexts; border >= 1, no flag paths).
+// k_raymarch nests "for every metavoxel the ray meets { for every sample in it }": the 64 rays of a wave enter, cross and leave a metavoxel
+// at different lattice indices, and a lane that has finished ITS samples of the metavoxel idles until the slowest ray of the wave has
+// finished (59 % of the lanes of a wave-sample hold a sample at the benchmark view; scripts/lane_bound.py: 93 % if a lane only ever
+// idled once its whole ray is done).  Here every lane is a small state machine -- "looking for my next metavoxel" / "sampling it" -- and the
+// wave alternates between two phases: lanes without a metavoxel advance their cell walk to the next occupied cell and set that metavoxel up
+// (the reference's per-draw arithmetic, unchanged), then every lane that has one takes its next two lattice samples.  A lane whose
+// metavoxel is exhausted blends it and rejoins at the next advance phase instead of waiting for its neighbours.
+// Same arithmetic in the same order per ray as k_raymarch (the image is bit-identical, the executed samples are the oracle's).  The
+// reference's global draw order is taken as the order along the ray (ranks ascend along it); a ray that meets a lower rank after a higher one
+// (rare: k_raymarch rolls such a slab back) is marched afresh by the selection-by-rank loop at the end.
+template <int NV, bool GREY>
+struct FlatMv {                 // the metavoxel a lane is sampling
+    const uint2* brick;
+    float f0x, f0y, f0z;        // texel coordinate of lattice index 0 (affine: texel(si) = f0 + si * fs)
+    float si, tEntry, tCamera;  // next lattice index (counting down, back to front), first index of the interval, camera index: exact integers
+    float rr, rg, rb, trans;    // the reference's back-to-front accumulators of this metavoxel (RM.shader:244-275)
+    int bi;
+};
+
+template <int NV, bool PARTIAL, bool GREY>
+__global__ void __launch_bounds__(64, VPFX_RM_WAVES)
+k_raymarch_flat(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
+                const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
+                unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out,
+                RmHandoff ho)
+{
+    const int lane = threadIdx.x;
+    constexpr int LX = VPFX_RM_LX, LY = VPFX_RM_LY, WPS = 4 << (LX + LY);
+    const int tgx = (k.W + 15) >> 4, tgy = (k.H + 15) >> 4;
+    const int sgx = (tgx + (1 << LX) - 1) >> LX, sgy = (tgy + (1 << LY) - 1) >> LY;
+    const int q = (int)(blockIdx.x >> 3);
+    const int within = q % WPS, wave = within & 3, j = within >> 2;
+    const int slot = (q / WPS) * 8 + (int)(blockIdx.x & 7u);
+    if (slot >= sgx * sgy) return;
+    const int sti = tile_order ? tile_order[slot] : slot;
+    const int ttx = ((sti % sgx) << LX) + (j & ((1 << LX) - 1)), tty = ((sti / sgx) << LY) + (j >> LX);
+    if (ttx >= tgx || tty >= tgy) return;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int col = ttx * 16 + (wave & 1) * 8 + lx;
+    const int row = tty * 16 + (wave >> 1) * 8 + ly;
+    if (col >= k.W || row >= k.H) return;
+
+    const RayCtx R = ray_setup(k, col, row, scene_depth);
+    const size_t pi = (size_t)row * k.W + col;
+    F4 dst{0.f, 0.f, 0.f, 0.f};
+    bool storedA = false;
+    int nsamp = 0;
+    float tg0, tg1;
+    {
+        const float bx0 = R.ivx * (0.f - R.ogx), bx1 = R.ivx * ((float)k.Nx - R.ogx);
+        const float by0 = R.ivy * (0.f - R.ogy), by1 = R.ivy * ((float)k.Ny - R.ogy);
+        const float bz0 = R.ivz * ((float)k.z0 - R.ogz), bz1 = R.ivz * ((float)k.z1 - R.ogz);
+        tg0 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+        tg1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+        tg0 = fmaxf(tg0, ((float)R.tCameraG - 2.0f) * k.mvStep);
+    }
+    const int nxy = k.Nx * k.Ny;
+    float tin = 1.0f, aA = 0.f;
+    const float cutoff = (PARTIAL && ho.t_in) ? VPFX_RM_HANDOFF_CUTOFF : k.alpha_cutoff;
+    bool alive = tg0 <= tg1;                       // still has metavoxels to look for or to sample
+    if (PARTIAL && ho.t_in) {
+        int code = 0;
+        for (int jj = 0; jj < ho.n_in; ++jj) code += ho.t_in[(size_t)jj * ho.plane + pi];
+        tin = __builtin_amdgcn_exp2f(-0.125f * (float)code);
+        if (early_out && tin <= cutoff) alive = false;
+    }
+    const int nslab = k.z1 - k.z0;
+    const int nA = min(max(k.zB - k.z0 + 1, 0), nslab);
+    const int max_cells = 2 * (k.Nx + k.Ny) + 8;
+    // per-ray constants of the sampling (march_mv): texel step per lattice index
+    const float fsx = (k.mvStep * R.dx) * k.texScale, fsy = (k.mvStep * R.dy) * k.texScale, fsz = (k.mvStep * R.dz) * k.texScale;
+
+    // lane state
+    int it = -1, zz = 0, wcx = 0, wcy = 0, walked = 0, last = -1, ns_layer = 0;
+    float ta = 0.f, tb = 0.f;
+    bool in_layer = false, wfin = false, in_mv = false, slow = false;
+    FlatMv<NV, GREY> m{};
+
+    auto walk_step = [&](int& cx, int& cy, bool& fin) -> int {
+        const float tx = R.dgx != 0.f ? R.ivx * ((float)cx + ((R.dgx > 0.f ? 1.0f : 0.0f) - R.ogx)) : 3.0e38f;
+        const float ty = R.dgy != 0.f ? R.ivy * ((float)cy + ((R.dgy > 0.f ? 1.0f : 0.0f) - R.ogy)) : 3.0e38f;
+        const int cur = (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) ? cy * k.Nx + cx : -1;
+        fin = !(fminf(tx, ty) < tb);
+        const bool stepx = tx < ty;
+        cx += stepx ? (R.dgx > 0.f ? 1 : -1) : 0;
+        cy += stepx ? 0 : (R.dgy > 0.f ? 1 : -1);
+        return cur;
+    };
+    // the slab's layer is finished: profile, early-out (the single-GPU rule, or the hand-off's bound)
+    auto end_layer = [&]() {
+        in_layer = false;
+        if (PARTIAL && ho.zsamples && nsamp != ns_layer)
+            atomicAdd(ho.zsamples + (blockIdx.x & (VPFX_ZPROF_COPIES - 1)) * k.Nz + zz, (unsigned)(nsamp - ns_layer));
+        if (early_out && (PARTIAL ? (1.0f - dst.w) * tin : 1.0f - dst.w) <= cutoff) alive = false;
+    };
+
+    for (;;) {
+        // ---- advance: lanes without a metavoxel look for their next one ---------------------------------------------------------
+        // Finding and setting up a metavoxel is a chain of dependent loads (cell occupancy -> rank, translation): ~2 000 cycles in which the
+        // whole wave stalls.  Run per lane the moment it becomes idle, that chain ran every other iteration (3.85 ms at C3 against
+        // 0.97 for the nested kernel).  So idle lanes WAIT until VPFX_FLAT_BATCH of them can advance together -- or nobody can sample.
+#ifndef VPFX_FLAT_BATCH
+#define VPFX_FLAT_BATCH 16
+#endif
+        const unsigned long long want = __builtin_amdgcn_ballot_w64(alive && !in_mv);
+        const bool go = __builtin_popcountll(want) >= VPFX_FLAT_BATCH || !__builtin_amdgcn_ballot_w64(in_mv);
+        if (go && alive && !in_mv) {
+            for (;;) {
+                if (!in_layer) {
+                    if (++it >= nslab) { alive = false; break; }
+                    zz = it < nA ? k.z0 + nA - 1 - it : k.z0 + it;
+                    if (R.dgz != 0.f) {
+                        const float a = R.ivz * ((float)zz - R.ogz), b = R.ivz * ((float)(zz + 1) - R.ogz);
+                        ta = fmaxf(fminf(a, b), tg0); tb = fminf(fmaxf(a, b), tg1);
+                    } else {
+                        if ((int)floorf(R.ogz) != zz) continue;
+                        ta = tg0; tb = tg1;
+                    }
+                    if (!(ta <= tb)) continue;
+                    if (PARTIAL && !(zz <= k.zB) && !storedA) {          // first phase-B slice of a slab: the phase-A image is complete
+                        img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+                        aA = dst.w;
+                        tin *= 1.0f - dst.w;
+                        dst = F4{0.f, 0.f, 0.f, 0.f};
+                        storedA = true;
+                    }
+                    wcx = (int)floorf(fmaf(ta, R.dgx, R.ogx)); wcy = (int)floorf(fmaf(ta, R.dgy, R.ogy));
+                    wfin = false; walked = 0; last = -1; in_layer = true; ns_layer = nsamp;
+                }
+                // next occupied cell along the ray inside this slice
+                int cell = -1;
+                const int* occ = brick_index + zz * nxy;
+                while (!wfin && walked < max_cells) {
+                    const int c = walk_step(wcx, wcy, wfin);
+                    ++walked;
+                    if (c >= 0 && occ[c] >= 0) { cell = c; break; }
+                }
+                if (cell < 0) { end_layer(); if (!alive) break; continue; }
+                const int r = rank[cell];
+                if (r <= last) { slow = true; alive = false; break; }    // the draw order is not the order along this ray: redone below
+                last = r;
+                // ---- set the metavoxel up: RM.shader frag (166-240), arithmetic as in march_mv ---------------------------------------
+                const int bi = occ[cell];
+                const float4 tr = mvtrans[bi];
+                const float ox = R.lx + tr.x, oy = R.ly + tr.y, oz = R.lz + tr.z;
+                const float tbx = R.idx * (-0.5f - ox), tby = R.idy * (-0.5f - oy), tbz = R.idz * (-0.5f - oz);
+                const float ttx2 = R.idx * (0.5f - ox), tty2 = R.idy * (0.5f - oy), ttz2 = R.idz * (0.5f - oz);
+                const float tminx = fminf(ttx2, tbx), tminy = fminf(tty2, tby), tminz = fminf(ttz2, tbz);
+                const float tmaxx = fmaxf(ttx2, tbx), tmaxy = fmaxf(tty2, tby), tmaxz = fmaxf(ttz2, tbz);
+                const float t1 = fmaxf(fmaxf(tminx, tminy), fmaxf(tminx, tminz));
+                const float t2 = fminf(fminf(tmaxx, tmaxy), fminf(tmaxx, tmaxz));
+                if (t1 > t2) continue;
+                const float exitDepth = -(R.startz + R.dirz * (t2 * k.s));
+                if (!(exitDepth > k.nearc) || !(exitDepth <= k.farc) || !(exitDepth < R.sceneDepth)) continue;
+                int tEntry = (int)ceilf(t1 / k.mvStep);
+                const int tExit = (int)floorf(t2 / k.mvStep);
+                const float cx = tr.x - ox, cy = tr.y - oy, cz = tr.z - oz;
+                const int tCamera = (int)(sqrtf((cx * cx + cy * cy) + cz * cz) / k.mvStep);
+                tEntry = max(tEntry, tCamera);
+                // a fragment with an empty interval still blends (0, 0, 0, 0): a no-op under UNDER, skipped
+                if (tExit < tEntry) continue;
+                nsamp += tExit - tEntry + 1;
+                brick_hit[bi] = 1;
+                m.brick = bricks + (size_t)bi * NV * NV * NV;
+                m.f0x = fmaf(ox + 0.5f, k.texScale, k.texBias); m.f0y = fmaf(oy + 0.5f, k.texScale, k.texBias); m.f0z = fmaf(oz + 0.5f, k.texScale, k.texBias);
+                m.si = (float)tExit; m.tEntry = (float)tEntry; m.tCamera = (float)tCamera;
+                m.rr = m.rg = m.rb = 0.f; m.trans = 1.0f; m.bi = bi;
+                in_mv = true;
+                break;
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(alive)) break;                  // every lane of the wave is finished (or waits for the slow path)
+        // ---- sample: every lane that has a metavoxel takes its next two lattice samples (back to front) ------------------------------
+        if (in_mv) {
+            struct Addr { const uint2* p; float wx, wy, wz; };
+            auto address = [&](float fi) -> Addr {
+                const float fx = fmaf(fi, fsx, m.f0x), fy = fmaf(fi, fsy, m.f0y), fz = fmaf(fi, fsz, m.f0z);
+                const float x0 = floorf(fx), y0 = floorf(fy), z0 = floorf(fz);
+                Addr a;
+                a.wx = fx - x0; a.wy = fy - y0; a.wz = fz - z0;
+                a.p = m.brick + (int)fmaf(fmaf(z0, (float)NV, y0), (float)NV, x0);
+                return a;
+            };
+            auto blend = [&](float cr, float cg, float cb, float density) {
+                const float bf = __builtin_amdgcn_rcpf(1.0f + density);
+                m.rr = fmaf(bf, m.rr - cr, cr);
+                if (!GREY) { m.rg = fmaf(bf, m.rg - cg, cg); m.rb = fmaf(bf, m.rb - cb, cb); }
+                m.trans *= bf;
+            };
+            // soft particles (RM.shader:267-270) fade the `soft` lattice points nearest the camera; whether a lane is there is per lane,
+            // whether the wave has to look is wave-uniform (never, for a camera outside the volume)
+            const bool two = m.si - 1.0f >= m.tEntry;
+            const bool in_soft = (m.si - (two ? 1.0f : 0.0f)) - m.tCamera < (float)k.soft;
+            const bool any_soft = __builtin_amdgcn_ballot_w64(in_soft) != 0;
+            const Addr a0 = address(m.si), a1 = address(two ? m.si - 1.0f : m.si);
+            auto fade = [&](float den, float fi) { const float dc = fi - m.tCamera; return dc < (float)k.soft ? den * (dc * k.inv_soft) : den; };
+            if (GREY) {
+                u32x4 u0, u1, v0, v1;
+                issue_load16<0>(u0, a0.p); issue_load16<NV * 8>(u1, a0.p);
+                issue_load16<0>(v0, a1.p); issue_load16<NV * 8>(v1, a1.p);
+                wait_pair<2>(u0, u1);
+                {
+                    const float ay = 1.0f - a0.wy, az = 1.0f - a0.wz;
+                    const float w00 = ay * az, w10 = a0.wy * az, w01 = ay * a0.wz, w11 = a0.wy * a0.wz;
+                    const float l0 = mix_fma_lo(w11, u1[1], mix_fma_lo(w01, u0[1], mix_fma_lo(w10, u1[0], mix_fma_lo(w00, u0[0], 0.f))));
+                    const float l1 = mix_fma_lo(w11, u1[3], mix_fma_lo(w01, u0[3], mix_fma_lo(w10, u1[2], mix_fma_lo(w00, u0[2], 0.f))));
+                    const float d0 = mix_fma_hi(w11, u1[1], mix_fma_hi(w01, u0[1], mix_fma_hi(w10, u1[0], mix_fma_hi(w00, u0[0], 0.f))));
+                    const float d1 = mix_fma_hi(w11, u1[3], mix_fma_hi(w01, u0[3], mix_fma_hi(w10, u1[2], mix_fma_hi(w00, u0[2], 0.f))));
+                    const float lum = lerpf(l0, l1, a0.wx), den = lerpf(d0, d1, a0.wx);
+                    blend(lum, lum, lum, any_soft ? fade(den, m.si) : den);
+                }
+                wait_pair<0>(v0, v1);
+                if (two) {
+                    const float ay = 1.0f - a1.wy, az = 1.0f - a1.wz;
+                    const float w00 = ay * az, w10 = a1.wy * az, w01 = ay * a1.wz, w11 = a1.wy * a1.wz;
+                    const float l0 = mix_fma_lo(w11, v1[1], mix_fma_lo(w01, v0[1], mix_fma_lo(w10, v1[0], mix_fma_lo(w00, v0[0], 0.f))));
+                    const float l1 = mix_fma_lo(w11, v1[3], mix_fma_lo(w01, v0[3], mix_fma_lo(w10, v1[2], mix_fma_lo(w00, v0[2], 0.f))));
+                    const float d0 = mix_fma_hi(w11, v1[1], mix_fma_hi(w01, v0[1], mix_fma_hi(w10, v1[0], mix_fma_hi(w00, v0[0], 0.f))));
+                    const float d1 = mix_fma_hi(w11, v1[3], mix_fma_hi(w01, v0[3], mix_fma_hi(w10, v1[2], mix_fma_hi(w00, v0[2], 0.f))));
+                    const float lum = lerpf(l0, l1, a1.wx), den = lerpf(d0, d1, a1.wx);
+                    blend(lum, lum, lum, any_soft ? fade(den, m.si - 1.0f) : den);
+                }
+            } else {
+                u32x4 u0, u1, u2, u3, v0, v1, v2, v3;
+                const uint2* z0p = a0.p + NV * NV; const uint2* z1p = a1.p + NV * NV;
+                issue_load16<0>(u0, a0.p); issue_load16<NV * 8>(u1, a0.p); issue_load16<0>(u2, z0p); issue_load16<NV * 8>(u3, z0p);
+                issue_load16<0>(v0, a1.p); issue_load16<NV * 8>(v1, a1.p); issue_load16<0>(v2, z1p); issue_load16<NV * 8>(v3, z1p);
+                auto filt = [&](const u32x4& t00, const u32x4& t10, const u32x4& t01, const u32x4& t11, const Addr& a, float fi) {
+                    const float ay = 1.0f - a.wy, az = 1.0f - a.wz;
+                    const float w00 = ay * az, w10 = a.wy * az, w01 = ay * a.wz, w11 = a.wy * a.wz;
+                    const float r0 = mix_fma_lo(w11, t11[0], mix_fma_lo(w01, t01[0], mix_fma_lo(w10, t10[0], mix_fma_lo(w00, t00[0], 0.f))));
+                    const float r1 = mix_fma_lo(w11, t11[2], mix_fma_lo(w01, t01[2], mix_fma_lo(w10, t10[2], mix_fma_lo(w00, t00[2], 0.f))));
+                    const float g0 = mix_fma_hi(w11, t11[0], mix_fma_hi(w01, t01[0], mix_fma_hi(w10, t10[0], mix_fma_hi(w00, t00[0], 0.f))));
+                    const float g1 = mix_fma_hi(w11, t11[2], mix_fma_hi(w01, t01[2], mix_fma_hi(w10, t10[2], mix_fma_hi(w00, t00[2], 0.f))));
+                    const float b0 = mix_fma_lo(w11, t11[1], mix_fma_lo(w01, t01[1], mix_fma_lo(w10, t10[1], mix_fma_lo(w00, t00[1], 0.f))));
+                    const float b1 = mix_fma_lo(w11, t11[3], mix_fma_lo(w01, t01[3], mix_fma_lo(w10, t10[3], mix_fma_lo(w00, t00[3], 0.f))));
+                    const float q0 = mix_fma_hi(w11, t11[1], mix_fma_hi(w01, t01[1], mix_fma_hi(w10, t10[1], mix_fma_hi(w00, t00[1], 0.f))));
+                    const float q1 = mix_fma_hi(w11, t11[3], mix_fma_hi(w01, t01[3], mix_fma_hi(w10, t10[3], mix_fma_hi(w00, t00[3], 0.f))));
+                    const float den = lerpf(q0, q1, a.wx);
+                    blend(lerpf(r0, r1, a.wx), lerpf(g0, g1, a.wx), lerpf(b0, b1, a.wx), any_soft ? fade(den, fi) : den);
+                };
+                wait_quad<4>(u0, u1, u2, u3);
+                filt(u0, u1, u2, u3, a0, m.si);
+                wait_quad<0>(v0, v1, v2, v3);
+                if (two) filt(v0, v1, v2, v3, a1, m.si - 1.0f);
+            }
+            m.si -= 2.0f;
+            if (m.si < m.tEntry) {
+                // the metavoxel is done: src = (rgb, 1 - T) premultiplied (RM.shader:301), blended UNDER (VPR.cs:688-691)
+                if (GREY) { m.rg = m.rr; m.rb = m.rr; }
+                const float sa = 1.0f - m.trans, ia = 1.0f - dst.w;
+                dst.x = m.rr * ia + dst.x; dst.y = m.rg * ia + dst.y; dst.z = m.rb * ia + dst.z; dst.w = sa * ia + dst.w;
+                in_mv = false;
+            }
+        }
+    }
+
+    // ---- rays whose draw order is not their depth order: marched afresh, metavoxels selected by rank within every slice (the reference's
+    //      literal order; O(cells^2) walks, rare) ---------------------------------------------------------------------------------------
+    if (slow) {
+        dst = F4{0.f, 0.f, 0.f, 0.f}; storedA = false; nsamp = 0; aA = 0.f;
+        float tin2 = 1.0f;
+        if (PARTIAL && ho.t_in) { int code = 0; for (int jj = 0; jj < ho.n_in; ++jj) code += ho.t_in[(size_t)jj * ho.plane + pi]; tin2 = __builtin_amdgcn_exp2f(-0.125f * (float)code); }
+        bool done = false;
+        for (int it2 = 0; it2 < nslab && !done; ++it2) {
+            const int z2 = it2 < nA ? k.z0 + nA - 1 - it2 : k.z0 + it2;
+            float sa, sb;
+            if (R.dgz != 0.f) {
+                const float a = R.ivz * ((float)z2 - R.ogz), b = R.ivz * ((float)(z2 + 1) - R.ogz);
+                sa = fmaxf(fminf(a, b), tg0); sb = fminf(fmaxf(a, b), tg1);
+            } else {
+                if ((int)floorf(R.ogz) != z2) continue;
+                sa = tg0; sb = tg1;
+            }
+            if (!(sa <= sb)) continue;
+            if (PARTIAL && !(z2 <= k.zB) && !storedA) {
+                img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+                aA = dst.w; tin2 *= 1.0f - dst.w;
+                dst = F4{0.f, 0.f, 0.f, 0.f}; storedA = true;
+            }
+            const int* occ = brick_index + z2 * nxy;
+            const int ns0 = nsamp;
+            int lastr = -1;
+            tb = sb;                                           // walk_step reads the slice's end from tb
+            for (;;) {
+                int best_r = 0x7fffffff, best_cell = -1, cx = (int)floorf(fmaf(sa, R.dgx, R.ogx)), cy = (int)floorf(fmaf(sa, R.dgy, R.ogy));
+                bool fin = false;
+                for (int guard = 0; guard < max_cells && !fin; ++guard) {
+                    const int c = walk_step(cx, cy, fin);
+                    if (c >= 0 && occ[c] >= 0) { const int r = rank[c]; if (r > lastr && r < best_r) { best_r = r; best_cell = c; } }
+                }
+                if (best_cell < 0) break;
+                lastr = best_r;
+                const int bi = occ[best_cell];
+                F4 src;
+                const int nsb = nsamp;
+                if (!march_mv<NV, false, false, GREY>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+                if (nsamp != nsb) brick_hit[bi] = 1;
+                const float ia = 1.0f - dst.w;
+                dst.x = src.x * ia + dst.x; dst.y = src.y * ia + dst.y; dst.z = src.z * ia + dst.z; dst.w = src.w * ia + dst.w;
+            }
+            if (PARTIAL && ho.zsamples && nsamp != ns0)
+                atomicAdd(ho.zsamples + (blockIdx.x & (VPFX_ZPROF_COPIES - 1)) * k.Nz + z2, (unsigned)(nsamp - ns0));
+            if (early_out && (PARTIAL ? (1.0f - dst.w) * tin2 : 1.0f - dst.w) <= cutoff) done = true;
+        }
+    }
+
+    if (PARTIAL && storedA) {
+        img_under[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+    } else {
+        img_over[pi] = make_float4(dst.x, dst.y, dst.z, dst.w);
+        if (PARTIAL) img_under[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (PARTIAL && ho.t_out0) {
         auto encode = [](float t) { return (uint8_t)(int)fminf(-8.0f * __builtin_amdgcn_logf(t), 255.0f); };
         const float t0 = storedA ? 1.0f - aA : 1.0f - dst.w;
         ho.t_out0[pi] = encode(t0);
@@ -751,6 +1106,23 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
 #endif
     const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
     hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS, GREY>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
+                       c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out, ho,
+                       (const float4*)c->d_cellinfo);
+}
+
+template <int NV, bool PARTIAL, bool GREY>
+void launch_rm_flat(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
+{
+    const int nsuper = rm_num_super_tiles(k.W, k.H);
+    const int* order = nullptr;
+    if (nsuper <= RM_ORDER_MAX) {
+        float* cost = reinterpret_cast<float*>(c->d_tile_order + nsuper + 8);
+        hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, rm_super_tiles_x(k.W), cost);
+        hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
+        order = c->d_tile_order;
+    }
+    const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
+    hipLaunchKernelGGL((k_raymarch_flat<NV, PARTIAL, GREY>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
                        c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out, ho);
 }
 
@@ -758,6 +1130,11 @@ template <int NV>
 void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
 {
     const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
+    if (c->rm_flat && !wrap && !k.flags) { // the wave-coherent traversal (border >= 1, no debug views / UNORM8 emulation)
+        if (c->bricks_grey) { if (d_under) launch_rm_flat<NV, true, true>(c, k, d_over, d_under, early_out, ho); else launch_rm_flat<NV, false, true>(c, k, d_over, d_under, early_out, ho); }
+        else { if (d_under) launch_rm_flat<NV, true, false>(c, k, d_over, d_under, early_out, ho); else launch_rm_flat<NV, false, false>(c, k, d_over, d_under, early_out, ho); }
+        return;
+    }
     const int sel = (d_under ? 4 : 0) | (wrap ? 2 : 0) | (k.flags ? 1 : 0);
     if (c->bricks_grey) {                  // (luminance, density) bricks: only ever filled with border >= 1
         switch (sel & 5) {
@@ -801,8 +1178,14 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under,
         c->brick_hit_cap = (size_t)nocc + nocc / 8 + 16;
     }
     VP_HIP(hipMemsetAsync(c->d_brick_hit, 0, c->brick_hit_cap * sizeof(int), c->stream));
+#if VPFX_RM_CELLINFO
+    // every cell's record starts out "empty" (slot -1), also when nothing is occupied: the walk reads the record of every cell it crosses
+    if (!c->d_cellinfo) VP_HIP(hipMalloc((void**)&c->d_cellinfo, c->n3 * sizeof(float4)));
+    VP_HIP(hipMemsetAsync(c->d_cellinfo, 0xff, c->n3 * sizeof(float4), c->stream));
+#endif
     if (nocc > 0) {
-        hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans);
+        hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans,
+                           c->d_cellinfo);
         if (k.flags & VP_RM_SHOW_DRAW_ORDER)
             hipLaunchKernelGGL(k_order_index, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_brick_index, c->d_rank,
                                nocc, c->d_mvtrans);

@@ -107,6 +107,7 @@ struct vp_ctx {
     vp_config cfg{};
     vp_multi* multi = nullptr;    // non-null: a fan-out context (its slabs live in child contexts); every entry point forwards
     bool test_chain_timeout = false;
+    bool rm_flat = false;         // VPFX_RM_FLAT=1 at vp_create: the wave-coherent ray-march traversal (k_raymarch_flat) -- A/B switch
     bool no_zprofile = false;     // VPFX_NO_ZPROFILE=1 in the environment at vp_create: measurement switch, slab ray-march without the per-slice sample profile
     int device = 0;
     hipStream_t stream = nullptr;
@@ -176,6 +177,7 @@ struct vp_ctx {
     // raymarch
     float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
     size_t mvtrans_cap = 0;
+    float4* d_cellinfo = nullptr; // [N^3] (translation, brick slot | -1) per cell: VPFX_RM_CELLINFO A/B variant of the cell walk
     int* d_rank = nullptr;        // [Ny*Nx]
     int* d_tile_order = nullptr;  // [2 x (super-tiles + 8)] dispatch order of k_raymarch (most expensive first), then the float cost estimates
     int* h_rank = nullptr;
