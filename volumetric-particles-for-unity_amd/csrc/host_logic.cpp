@@ -202,6 +202,10 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
         k->c2g[r * 4 + 3] = (float)(acc / (double)g.s + 0.5);
         k->camg[r] = k->c2g[r * 4 + 3];
     }
+    // Brick rows run along grid x.  A lane quad (four consecutive lanes) costs one L1 cycle when its four footprint loads share a 128-byte
+    // line, so consecutive lanes should step along the SCREEN axis on which grid x changes fastest: screen x normally, screen y when the
+    // view is rolled (d grid-x / d camera-y dominates).  Scheduling only; the image does not depend on it.
+    k->lane_transpose = std::fabs(k->c2g[1]) > std::fabs(k->c2g[0]) ? 1 : 0;
     k->texScale = (float)(g.nv - 2 * g.b);      // tc = (p + 0.5)(1 - 2b/nv) + b/nv; texel = tc*nv - 0.5   RM.shader:255-258
     k->texBias = (float)g.b - 0.5f;
     k->inv_soft = 1.0f / (float)rp->soft_distance;                           // rcp(_SoftDistance)       RM.shader:269

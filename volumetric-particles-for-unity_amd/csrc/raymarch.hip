@@ -469,7 +469,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     // lanes row-major in the tile: the L1 serves a wave-load one lane quad per cycle when the quad's addresses share a 128-B line
     // (scripts/probes/l1_gather_probe.hip), and four pixels in a screen row share a brick row more often than a 2 x 2 px quad does
     // (Z-order lanes: 1.62 ms against 1.46).
-    const int lx = lane & 7, ly = lane >> 3;
+    const int lx = k.lane_transpose ? lane >> 3 : lane & 7, ly = k.lane_transpose ? lane & 7 : lane >> 3;   // (hl_build_rm_consts)
     const int col = ttx * 16 + (wave & 1) * 8 + lx;
     const int row = tty * 16 + (wave >> 1) * 8 + ly;
     if (col >= k.W || row >= k.H) return;
@@ -721,7 +721,7 @@ k_raymarch_flat(RmConsts k, const int* __restrict__ brick_index, const uint2* __
     const int sti = tile_order ? tile_order[slot] : slot;
     const int ttx = ((sti % sgx) << LX) + (j & ((1 << LX) - 1)), tty = ((sti / sgx) << LY) + (j >> LX);
     if (ttx >= tgx || tty >= tgy) return;
-    const int lx = lane & 7, ly = lane >> 3;
+    const int lx = k.lane_transpose ? lane >> 3 : lane & 7, ly = k.lane_transpose ? lane & 7 : lane >> 3;   // (hl_build_rm_consts)
     const int col = ttx * 16 + (wave & 1) * 8 + lx;
     const int row = tty * 16 + (wave >> 1) * 8 + ly;
     if (col >= k.W || row >= k.H) return;

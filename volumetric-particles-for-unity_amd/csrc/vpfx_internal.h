@@ -58,7 +58,7 @@ struct FillConsts {
 struct RmConsts {
     int W, H, Nx, Ny, Nz, nv, z0, z1;
     int zB, steps, soft, partial;
-    int flags, num_covered, pad2, pad3;  // VP_RM_* bits of vp_raymarch_params.flags; _NumMetavoxelsCovered (VPR.cs:755)
+    int flags, num_covered, lane_transpose, pad3;  // VP_RM_* bits of vp_raymarch_params.flags; _NumMetavoxelsCovered (VPR.cs:755); lanes run down screen columns
     float aspect, neg_inv_tan, zMin, s;
     float mvStep, inv_mvStep, nearc, farc;
     float c2m_lin[9];             // linear part of _CameraToMetavoxel (identical for every MV), rows     VPR.cs:778
