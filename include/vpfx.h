@@ -240,7 +240,11 @@ int  vp_fill(vp_ctx* ctx, const vp_fill_params* params);
  *                        reaches it from the light-propagation map and writing the transmitted light back
  *                        (Fill.shader:224, 250).  An empty metavoxel is a no-op (the reference never calls it for one,
  *                        VPR.cs:511).  Calling it for every occupied metavoxel in zz-major order after vp_fill_begin
- *                        reproduces vp_fill bit for bit. */
+ *                        reproduces vp_fill: bit for bit with an f32 cube map; within 1 fp16 ulp with an R8 map (vp_fill keeps
+ *                        that one in LDS as bytes and folds 1/255 into the displacement scale, the per-metavoxel kernel filters
+ *                        byte/255 floats from the global table: the same value up to rounding).
+ *   A vp_fill_begin whose ambient colour changes the bricks' storage format (grey z-pair entries <-> RGBA16F) clears every
+ *   brick first: a partial refill must never leave bricks of two formats in one pool. */
 int  vp_fill_begin(vp_ctx* ctx, const vp_fill_params* params);
 int  vp_fill_metavoxel(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz);
 

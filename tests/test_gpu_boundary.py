@@ -171,6 +171,44 @@ def test_per_metavoxel_entry_points_replay_the_reference_loops(cam_pos):
     assert (zb >= 0) == (cam_pos is not None)
 
 
+def test_per_metavoxel_fill_with_an_r8_cubemap_and_a_storage_format_change():
+    """vpfx.h: the per-metavoxel fill replays vp_fill within 1 fp16 ulp for R8 cube maps (vp_fill: LDS byte kernel; per metavoxel: float table);
+    and a vp_fill_begin that changes the brick storage format (grey ambient -> coloured) clears the pool, so a PARTIAL refill leaves cleared
+    bricks, never bricks of the other format read as garbage."""
+    sc = S.make_scene("T0", cubemap="r8")
+    e = E.Engine(sc.config())
+    e.set_frame(sc.light_to_world, sc.grid_center)
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    e.fill(sc.fill_params())
+    assert e.stats()["brick_format"] == 1                      # grey z-pair entries
+    cnt = e.bin_counts()
+    occ = list(zip(*np.nonzero(cnt)))
+    whole = {k: e.read_brick(k[2], k[1], k[0]).copy() for k in occ}
+    e.fill_begin(sc.fill_params())
+    for zz, yy, xx in occ:                                     # zz-major = the reference's loop
+        e.fill_metavoxel(xx, yy, zz)
+    for k in occ:
+        a, b = whole[k].view(np.uint16).astype(np.int32), e.read_brick(k[2], k[1], k[0]).view(np.uint16).astype(np.int32)
+        assert np.abs(a - b).max() <= 1, k
+    # now a coloured ambient and ONE metavoxel refilled: everything else must read as cleared RGBA16F, the refilled one as the oracle's brick
+    sc.ambient = (0.1, 0.3, 0.2)
+    e.fill_begin(sc.fill_params())
+    z0, y0, x0 = occ[0]
+    e.fill_metavoxel(x0, y0, z0)
+    assert e.stats()["brick_format"] == 0
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    a, b = o.read_brick(x0, y0, z0).view(np.uint16).astype(np.int32), e.read_brick(x0, y0, z0).view(np.uint16).astype(np.int32)
+    assert np.abs(a - b).max() <= 1
+    for zz, yy, xx in occ[1:]:
+        assert not e.read_brick(xx, yy, zz).view(np.uint16).any(), (xx, yy, zz)
+    img = e.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.isfinite(img).all() and img[..., 3].max() <= 1.0 + 1e-6
+    e.close()
+
+
 def test_fill_one_metavoxel_only_touches_that_metavoxel():
     sc = S.make_scene("T0")
     m = _manager(sc)
