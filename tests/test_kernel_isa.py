@@ -5,37 +5,56 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc", "fill.hip")
 
 
-def test_pipelined_footprint_loads_are_never_touched_before_their_wait():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py")], capture_output=True, text=True)
+@pytest.fixture(scope="module")
+def listings(tmp_path_factory):
+    """fill.hip and raymarch.hip compiled to gfx950 ISA ONCE each (over a minute for fill.hip): (listing file, resource remarks) per source."""
+    d = tmp_path_factory.mktemp("isa")
+    out = {}
+    for name in ("fill", "raymarch"):
+        asm = str(d / f"{name}.s")
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "--cuda-device-only",
+                            "-S", SRC.replace("fill.hip", name + ".hip"), "-o", asm, "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True, check=True)
+        out[name] = (asm, r.stderr)
+    return out
+
+
+def _check(which, listing):
+    env = dict(os.environ, VPFX_ASM_FILE=listing)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py")] + ([which] if which else []), capture_output=True, text=True,
+                          env=env)
+
+
+def test_pipelined_footprint_loads_are_never_touched_before_their_wait(listings):
+    r = _check(None, listings["fill"][0])
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"(\d+) pipelined loads, 0 violations", r.stdout)
     assert m and int(m.group(1)) > 100, r.stdout
 
 
-def test_lds_cubemap_reads_are_never_touched_before_their_wait():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py"), "fill_lds"], capture_output=True, text=True)
+def test_lds_cubemap_reads_are_never_touched_before_their_wait(listings):
+    r = _check("fill_lds", listings["fill"][0])
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"checked (\d+) k_fill_lds instantiations, (\d+) pipelined loads, 0 violations", r.stdout)
     assert m and int(m.group(1)) == 24 and int(m.group(2)) >= 600, r.stdout       # NV x MODE x TAB x (D == 1 variant)
 
 
-def test_raymarch_texel_loads_are_never_touched_before_their_wait():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_fill_asm.py"), "raymarch"], capture_output=True, text=True)
+def test_raymarch_texel_loads_are_never_touched_before_their_wait(listings):
+    r = _check("raymarch", listings["raymarch"][0])
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"(\d+) pipelined loads, 0 violations", r.stdout)
     assert m and int(m.group(1)) >= 96, r.stdout
 
 
-def test_fill_kernel_resources():
+def test_fill_kernel_resources(listings):
     """No scratch, register arrays addressed through s_set_gpr_idx (not compare/select chains), <= 168 VGPRs (3 waves/SIMD)."""
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                          "--cuda-device-only", "-S", SRC, "-o", "/dev/stdout", "-Rpass-analysis=kernel-resource-usage"],
-                         capture_output=True, text=True, check=True)
-    blocks = re.split(r"Function Name: ", out.stderr)[1:]
+    blocks = re.split(r"Function Name: ", listings["fill"][1])[1:]
     seen = 0
     for b in blocks:
         name = b.split()[0]
@@ -46,7 +65,7 @@ def test_fill_kernel_resources():
         # the default-math kernels must keep 3 waves/SIMD (512 / 3 = 170 VGPRs); the EXACT (parity-test) variants may take more
         assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 168, name
     assert seen == 27          # 18 chained (NV x {default, EXACT, D == 1} x MODE) + 9 column-range kernels of the per-metavoxel entry point
-    asm = out.stdout
+    asm = open(listings["fill"][0]).read()
     body = asm[asm.index("k_fillILi32ELi0ELi0"):]
     body = body[:body.index("s_endpgm")]
     assert body.count("s_set_gpr_idx_on") >= 8
@@ -62,17 +81,14 @@ def test_fill_kernel_resources():
         assert "buffer_wbl2" not in b and "buffer_inv" not in b, kern
 
 
-def test_raymarch_kernel_resources():
+def test_raymarch_kernel_resources(listings):
     """Every k_raymarch / k_raymarch_one instantiation: no scratch (round 1 spilled 12 VGPRs at 96 VGPRs / 5 waves), 4 waves/SIMD."""
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                          "--cuda-device-only", "-S", SRC.replace("fill.hip", "raymarch.hip"), "-o", "/dev/null",
-                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True)
     seen = 0
-    for b in re.split(r"Function Name: ", out.stderr)[1:]:
+    for b in re.split(r"Function Name: ", listings["raymarch"][1])[1:]:
         name = b.split()[0]
         if "k_raymarch" not in name:
             continue
         seen += 1
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
         assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= (168 if "ELb1ELb" in name and name.count("ELb1") >= 2 else 128), name
-    assert seen == 45          # 24 RGBA + 12 grey k_raymarch, 9 k_raymarch_one
+    assert seen == 57          # 24 RGBA + 12 grey k_raymarch, 9 k_raymarch_one, 12 k_raymarch_flat (A/B variant)
