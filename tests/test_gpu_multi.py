@@ -198,3 +198,42 @@ def test_partial_raymarch_handoff_entry_point_on_separate_contexts():
     assert np.all(dec >= true_t * (1 - 1e-6)) and np.all(dec <= np.maximum(true_t, 2.0 ** -31.9) * 2 ** 0.125 * (1 + 1e-6))
     for e in engs + [single]:
         e.close()
+
+
+def test_manager_mirror_on_a_fanout_context_with_occluders_and_render_target_emulation():
+    """The component mirror (manager.py = csharp/MetavoxelManager.cs) with a device list: the reference's frame loop (VPR.cs:181-220) over several
+    frames incl. a slab re-cut, occluder boxes (both depth inputs rendered on every slab's GPU) and the UNORM8 render-target emulation (flag
+    kernels: no hand-off), against the same manager on one context."""
+    from vpfx_amd import manager as M
+    sc = S.make_scene("C1", cubemap="r8")
+    box = abi.vp_obb()
+    box.center[0], box.center[1], box.center[2] = 0.0, -4.0, 2.0
+    for i, v in enumerate((1, 0, 0, 0, 1, 0, 0, 0, 1)):
+        box.axes[i] = v
+    box.half_extent[0], box.half_extent[1], box.half_extent[2] = 6.0, 1.0, 6.0
+    frames = {}
+    for name, devs in (("one", ()), ("fanout", (0, 0, 0))):
+        m = M.MetavoxelManager(sc.N[0], sc.N[1], sc.N[2], sc.mv_scale, sc.nv, sc.border, sc.width, sc.height, gpuDevices=devs,
+                               multiFlags=abi.VP_MULTI_PEER_COPY, rebalanceInterval=2)
+        m.lightToWorld = np.ascontiguousarray(sc.light_to_world, dtype=np.float32).reshape(-1)
+        m.wsGridCenter = np.asarray(sc.grid_center, dtype=np.float32)
+        m.psysLocalToWorld = np.ascontiguousarray(sc.psys_local_to_world, dtype=np.float32).reshape(-1)
+        m.displacementCubemap = sc.cubemap
+        m.Start()
+        m._engine.set_occluders([box])
+        out = []
+        for f in range(5):
+            out.append(m.OnPostRender(f, sc.particles, sc.layout, sc.camera()).copy())
+        rq = sc.raymarch_params()
+        rq.flags = abi.VP_RM_QUANTIZE_UNORM8
+        out.append(m._engine.raymarch(sc.camera(), rq))
+        frames[name] = out
+        if devs:
+            info = m._engine.multi_info()
+            assert info["world_size"] == 3 and info["slab_cuts"][-1] == sc.N[2]
+        m._engine.close()
+    for a, b in zip(frames["one"][:5], frames["fanout"][:5]):
+        assert np.abs(a - b).max() <= 2e-5
+    assert frames["one"][0][..., 3].max() > 0.1                                      # the occluder does not hide everything
+    # re-quantising after every blend is discontinuous: slab partial images quantise at other points than the single target (Q19)
+    assert np.abs(frames["one"][5] - frames["fanout"][5]).max() <= 4.01 / 255

@@ -30,7 +30,7 @@ from .engine import Engine
 
 class MetavoxelManager:
     def __init__(self, numMetavoxelsX=10, numMetavoxelsY=10, numMetavoxelsZ=10, mvScale=3.0, numVoxelsInMetavoxel=32,
-                 numBorderVoxels=1, screenWidth=1024, screenHeight=768, device=-1):
+                 numBorderVoxels=1, screenWidth=1024, screenHeight=768, device=-1, gpuDevices=(), multiFlags=0, rebalanceInterval=240):
         # ---- inspector fields (defaults = the demo scene, Volumetric_Particle_System.unity:9013-9026)
         self.numMetavoxelsX, self.numMetavoxelsY, self.numMetavoxelsZ = numMetavoxelsX, numMetavoxelsY, numMetavoxelsZ
         self.mvScale = float(mvScale)
@@ -44,6 +44,8 @@ class MetavoxelManager:
         self.opacityFactor = 0.04
         self.softParticleStepDistance = 20
         self.screenWidth, self.screenHeight, self.device = screenWidth, screenHeight, device
+        # ---- added by this binding (same names as csharp/MetavoxelManager.cs): the device list of a multi-GPU fan-out context
+        self.gpuDevices, self.multiFlags, self.rebalanceInterval = tuple(gpuDevices), multiFlags, rebalanceInterval
         # ---- scene bindings (dirLight, gridCenter, particleSys, displacement texture)
         self.lightToWorld = np.eye(4, dtype=np.float32).T.reshape(16).copy()
         self.wsGridCenter = np.zeros(3, dtype=np.float32)                       # VPR.cs:138
@@ -65,6 +67,13 @@ class MetavoxelManager:
         cfg.num_mv[0], cfg.num_mv[1], cfg.num_mv[2] = self.numMetavoxelsX, self.numMetavoxelsY, self.numMetavoxelsZ
         cfg.num_voxels, cfg.num_border, cfg.mv_scale = self.numVoxelsInMetavoxel, self.numBorderVoxels, self.mvScale
         cfg.width, cfg.height, cfg.device = self.screenWidth, self.screenHeight, self.device
+        if len(self.gpuDevices) > 1:                                            # the ONE thing a multi-GPU host adds
+            cfg.num_devices = len(self.gpuDevices)
+            for i, d in enumerate(self.gpuDevices):
+                cfg.devices[i] = d
+            cfg.multi_flags = self.multiFlags
+        elif len(self.gpuDevices) == 1:
+            cfg.device = self.gpuDevices[0]
         self._engine = Engine(cfg)
         self._frame_dirty = True
 
@@ -72,6 +81,8 @@ class MetavoxelManager:
         """VPR.cs:181-220.  Returns particlesRT (and composites it over mainSceneRT in place when given)."""
         # the reference's first OnPostRender has frameCount % updateInterval == 0 (frame 0); a host that starts on another frame
         # would ray-march textures that were never filled, so the first call always bins + fills
+        if len(self.gpuDevices) > 1 and self.rebalanceInterval > 0 and frameCount % self.rebalanceInterval == 0 and self._filled_once:
+            self._engine.rebalance()                                            # re-cut the slabs from the work the GPUs measured
         if frameCount % self.updateInterval == 0 or not self._filled_once:      # :186
             if self._frame_dirty:                                               # :188-195
                 self.UpdateMetavoxelPositions()
