@@ -1,0 +1,56 @@
+"""GPU: bench.py as the driver runs it -- a bare `python bench.py ...` must start by itself for every --gpus N it accepts on this box, print ONE
+JSON line with the contract's keys, and the N > 1 line must say which launch style ran, how many RCCL ranks the library's communicator reported
+and how far the sharded frame is from the 1-GPU frame."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+        "roofline")
+
+
+def _bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "4", "--warmup", "2"] + list(args), cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    return d
+
+
+def test_single_gpu_line_has_roofline_and_cpu_baseline():
+    d = _bench()
+    assert d["n_gpus"] == 1 and d["config"]["launch"] == "single GPU" and d["config"]["rccl_ranks"] is None
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "single_thread" in cb
+    assert d["stage_ms"]["bin"] + d["stage_ms"]["fill_kernel"] + d["stage_ms"]["raymarch_kernel"] <= d["ms_per_step"] * 1.02
+
+
+@pytest.mark.parametrize("n,exchange", [(2, "tiles"), (4, "all_gather")])
+def test_self_launching_fanout_on_one_gpu(n, exchange):
+    d = _bench("--gpus", str(n), "--share-gpu", "--exchange", exchange, "--no-cpu-baseline")
+    c = d["config"]
+    assert d["n_gpus"] == n and c["rccl_ranks"] == 0 and "peer-copy test hook" in c["launch"]
+    assert len(c["slabs"]) == n and c["slabs"][0][0] == 0 and c["slabs"][-1][1] == 8
+    assert c["max_abs_rgba_diff_vs_1gpu_frame"] is not None and c["max_abs_rgba_diff_vs_1gpu_frame"] <= 2e-5
+    assert d["exchange_ms"]["t_blend_image_exchange_and_blend"] > 0 and len(d["per_rank"]["samples"]) == n
+    assert d["scaling"] == "strong" and exchange in c["parallelism"]
+
+
+def test_more_gpus_than_the_box_has_is_refused_loudly():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "C1", "--steps", "2"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--share-gpu" in (r.stdout + r.stderr)
