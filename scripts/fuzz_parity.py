@@ -136,6 +136,23 @@ def one_case(seed):
         np.testing.assert_allclose(engs[-1].e.read_lightmap(), o.read_lightmap(), rtol=2e-5 if exact else 6e-5, atol=1e-9)
         for h in engs:
             h.e.close()
+        # the same scene through the fan-out INSIDE the library (csrc/multi.cpp) on this one GPU: random rank count, exchange, hand-off groups
+        wf = int(rng.integers(2, min(sc.N[2], 5) + 1))
+        mflags = abi.VP_MULTI_PEER_COPY | (abi.VP_MULTI_EXCHANGE_ALL_GATHER if rng.integers(0, 2) else 0) | (abi.VP_MULTI_UNIFORM_SLABS if rng.integers(0, 3) == 0 else 0)
+        mf = E.Engine(sc.config(devices=[0] * wf, multi_flags=mflags, rm_groups=int(rng.integers(0, wf + 1))), exact=exact)
+        mf.set_frame(sc.light_to_world, sc.grid_center)
+        mf.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        mf.fill(sc.fill_params())
+        imf = mf.raymarch(cam, rp)
+        assert float(np.abs(imf - io).max()) <= 1e-3 and float(np.abs(imf - ie).max()) <= 3e-5, f"fan-out({wf}) rgba {np.abs(imf - io).max()} / {np.abs(imf - ie).max()}"
+        assert np.array_equal(mf.bin_counts(), co), "fan-out bin counts"
+        mf.rebalance()
+        mf.raymarch(cam, rp)
+        mf.bin_resident(); mf.fill(sc.fill_params())
+        assert float(np.abs(mf.raymarch(cam, rp) - ie).max()) <= 3e-5, "fan-out after re-cut"
+        assert mf.stats()["samples"] <= sg
+        np.testing.assert_allclose(mf.read_lightmap(), o.read_lightmap(), rtol=2e-5 if exact else 6e-5, atol=1e-9)
+        mf.close()
         rq = sc.raymarch_params()
         rq.flags = abi.VP_RM_QUANTIZE_UNORM8
         iq_o, iq_g = o.raymarch(cam, rq), g.raymarch(cam, rq)
