@@ -165,7 +165,10 @@ def main():
     rank = int(os.environ.get("RANK", "0")) if multi_process else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if multi_process else 0
     if args.share_gpu and multi_process:
-        raise SystemExit("--share-gpu is the single-process test hook (python bench.py --gpus N --share-gpu)")
+        # rendezvous check only: every rank on cuda:0.  RCCL refuses two ranks on one GPU ("Duplicate GPU detected") -- AFTER its bootstrap has
+        # exchanged the peers' information, so getting that error back as VP_ERR_RCCL proves that the unique id travelled, that the ranks found
+        # each other and that failures surface instead of hanging (scripts/gpu_rendezvous_check.sh); the peer-copy hook needs one process
+        local_rank = 0
     ngpu = torch.cuda.device_count()
     if N > 1 and not multi_process and not args.share_gpu and ngpu < N:
         raise SystemExit(f"--gpus {N} but only {ngpu} GPU(s) visible (functional run on one GPU: add --share-gpu)")

@@ -54,3 +54,20 @@ def test_more_gpus_than_the_box_has_is_refused_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "C1", "--steps", "2"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "--share-gpu" in (r.stdout + r.stderr)
+
+
+def test_one_process_per_gpu_launch_meets_in_rccl_and_fails_cleanly_on_one_gpu():
+    """The driver's launch style (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with two ranks on this ONE GPU: RCCL
+    must refuse the communicator -- "Duplicate GPU detected", which it can only say after its bootstrap exchanged the ranks' information, i.e. after
+    rank 0's unique id reached rank 1 over the gloo group and the two met.  So VP_ERR_RCCL from both ranks within seconds proves the rendezvous path
+    (vp_rccl_unique_id -> broadcast -> vp_config.rccl_unique_id -> ncclCommInitRank) and that a communicator failure surfaces instead of hanging."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, MASTER_ADDR="127.0.0.1", NCCL_DEBUG="WARN")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--config", "C1", "--steps", "2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert out.count("VP_ERR_RCCL") >= 2, out[-3000:]                      # both ranks
+    assert "Duplicate GPU detected" in out, out[-3000:]
