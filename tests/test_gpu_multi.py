@@ -237,3 +237,38 @@ def test_manager_mirror_on_a_fanout_context_with_occluders_and_render_target_emu
     assert frames["one"][0][..., 3].max() > 0.1                                      # the occluder does not hide everything
     # re-quantising after every blend is discontinuous: slab partial images quantise at other points than the single target (Q19)
     assert np.abs(frames["one"][5] - frames["fanout"][5]).max() <= 4.01 / 255
+
+
+def test_config4_benchmark_grid_in_eight_slabs_through_the_library():
+    """BASELINE config 4 = the C3 workload (32^3 metavoxels x 32^3 voxels, 100 k particles, 1080p) on light-axis slabs, through the PRODUCT path: one
+    fan-out context with eight ranks (on this one GPU), the library's own work-balanced cut incl. a re-cut, against the single context (<= 2e-5),
+    the oracle's frame (<= 1e-3) and the sample-count bounds: never more than the oracle's lattice, and with a serial hand-off chain the single
+    GPU's executed samples (+- 2 %)."""
+    sc = S.make_scene("C3", cubemap="r8")
+    single, ref = _single(sc)
+    s1 = single.stats()["samples"]
+    o = O.Oracle(sc.config())
+    io = _frame(o, sc)
+    lattice = o.stats()["samples"]
+    cam, rp = sc.camera(), sc.raymarch_params()
+    for groups in (1, 8):
+        m = _fanout(sc, 8, groups=groups)
+        img = _frame(m, sc)
+        assert np.abs(img - ref).max() <= 2e-5 and np.abs(img - io).max() <= 1e-3, groups
+        m.rebalance()
+        m.raymarch(cam, rp)
+        m.bin_resident(); m.fill(sc.fill_params())
+        img = m.raymarch(cam, rp)
+        assert np.abs(img - ref).max() <= 2e-5 and np.abs(img - io).max() <= 1e-3, groups
+        info, st = m.multi_info(), m.stats()
+        cuts = info["slab_cuts"]
+        assert cuts[0] == 0 and cuts[-1] == 32 and all(b > a for a, b in zip(cuts, cuts[1:]))
+        assert st["occupied_mv"] == 11325 and st["pairs"] == 480441                    # SURVEY App. C: the slabs partition the grid's work
+        assert s1 <= st["samples"] * 1.02 and st["samples"] <= lattice
+        if groups == 8:
+            assert st["samples"] <= 1.02 * s1
+        else:
+            assert st["samples"] > 1.5 * s1                                            # without a hand-off the slabs behind march hidden samples
+        np.testing.assert_allclose(m.read_lightmap(), single.read_lightmap(), rtol=2e-5, atol=1e-9)
+        m.close()
+    single.close()
