@@ -8,9 +8,13 @@ load_package()
 from vpfx_amd import engine as E, scene as S
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-sc = S.make_scene(name)
+cube = sys.argv[3] if len(sys.argv) > 3 else "f32"          # r8: the LDS byte-table kernels (default math only)
+dscale = float(sys.argv[4]) if len(sys.argv) > 4 else None
+sc = S.make_scene(name, cubemap=cube)
+if dscale is not None:
+    sc.displacement_scale = dscale
 out = []
-for exact in (False, True):
+for exact in ((False,) if cube == "r8" else (False, True)):
     g = E.Engine(sc.config(), exact=exact)
     g.set_frame(sc.light_to_world, sc.grid_center)
     g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
@@ -25,4 +29,4 @@ for exact in (False, True):
         hs.add(h.hexdigest()[:16])
     out.append(f"{'exact' if exact else 'fast'} {sorted(hs)} {g.last_kernel_ms(1):.3f}ms")
     g.close()
-print(name, " | ".join(out))
+print(name, cube, " | ".join(out))

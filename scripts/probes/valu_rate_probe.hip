@@ -9,11 +9,12 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum { OP_FMA, OP_PKFMA, OP_MUL, OP_CUBEID, OP_CUBEMA, OP_RCP, OP_SQRT, OP_FLOOR, OP_FRACT, OP_CVTU, OP_MED3, OP_MAX, OP_CNDMASK,
-       OP_MIX, OP_DSADD, OP_DSMAX, OP_DSREAD, OP_MOVREL, OP_ALIGNBYTE, OP_CVTUB, OP_ADD, OP_SUB, OP_FMAC, OP_CMP, OP_MOV, OP_PKADD, OP_PKMUL, OP_ADDU, OP_MIN, OP_DSREADU8, OP_DSRMW, OP_CVTF16, OP_COUNT };
+       OP_MIX, OP_DSADD, OP_DSMAX, OP_DSREAD, OP_MOVREL, OP_ALIGNBYTE, OP_CVTUB, OP_ADD, OP_SUB, OP_FMAC, OP_CMP, OP_MOV, OP_PKADD, OP_PKMUL, OP_ADDU, OP_MIN, OP_DSREADU8, OP_DSRMW, OP_CVTF16, OP_MULDEN, OP_MULNRM, OP_SUBDEN, OP_PKMULDEN, OP_FMADEN, OP_COUNT };
 static const char* NAMES[] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_cubeid_f32", "v_cubema_f32", "v_rcp_f32", "v_sqrt_f32", "v_floor_f32",
                               "v_fract_f32", "v_cvt_u32_f32", "v_med3_f32", "v_max_f32", "v_cndmask_b32", "v_fma_mix_f32", "ds_add_f32", "ds_max_f32",
                               "ds_read_b32", "v_mov(gpr_idx)", "v_alignbyte_b32", "v_cvt_f32_ubyte1", "v_add_f32", "v_sub_f32", "v_fmac_f32", "v_cmp_le_f32", "v_mov_b32",
-                              "v_pk_add_f32", "v_pk_mul_f32", "v_add_u32", "v_min_f32", "ds_read_u8", "ds_read+add+ds_write", "v_cvt_f32_f16"};
+                              "v_pk_add_f32", "v_pk_mul_f32", "v_add_u32", "v_min_f32", "ds_read_u8", "ds_read+add+ds_write", "v_cvt_f32_f16",
+                              "v_mul_f32 denormal*K", "v_mul_f32 normal*K (same form)", "v_sub_f32 den-den", "v_pk_mul_f32 den*K", "v_fma_f32 K*den+den"};
 
 template <int OP>
 __device__ __forceinline__ void op(float& a, f2& a2, float b, float c, unsigned lds_addr)
@@ -42,6 +43,12 @@ __device__ __forceinline__ void op(float& a, f2& a2, float b, float c, unsigned 
     if (OP == OP_MIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a) : "v"(b));
     if (OP == OP_DSREADU8) asm volatile("ds_read_u8 %0, %1" : "=v"(a) : "v"(lds_addr) : "memory");
     if (OP == OP_DSRMW) { float t; asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_add_f32 %0, %0, %2\n ds_write_b32 %1, %0" : "=&v"(t) : "v"(lds_addr), "v"(b) : "memory"); }
+    // denormal operands (round 3: the fill treats ds_read_u8 results as denormal floats): non-chained forms, inputs stay denormal
+    if (OP == OP_MULDEN) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(lds_addr & 255u | 1u)), "v"(8.507059173023462e37f));
+    if (OP == OP_MULNRM) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a) : "v"(b), "v"(8.507059173023462e37f));
+    if (OP == OP_SUBDEN) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(lds_addr & 255u | 1u)), "v"(__uint_as_float(77u)));
+    if (OP == OP_PKMULDEN) { f2 d2 = {__uint_as_float(lds_addr & 255u | 1u), __uint_as_float(99u)}, k2 = {8.507059173023462e37f, 8.507059173023462e37f}; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(a2) : "v"(d2), "v"(k2)); }
+    if (OP == OP_FMADEN) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(__uint_as_float(lds_addr & 255u | 1u)), "v"(8.507059173023462e37f), "v"(__uint_as_float(55u)));
     if (OP == OP_CVTF16) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a));
     if (OP == OP_MIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,1,0]" : "+v"(a) : "v"(b), "v"(c));
     if (OP == OP_DSADD) asm volatile("ds_add_f32 %0, %1" : : "v"(lds_addr), "v"(b) : "memory");
@@ -118,6 +125,7 @@ int main()
     sweep<OP_RCP>(d_out, h); sweep<OP_SQRT>(d_out, h); sweep<OP_FLOOR>(d_out, h); sweep<OP_FRACT>(d_out, h); sweep<OP_CVTU>(d_out, h);
     sweep<OP_MED3>(d_out, h); sweep<OP_MAX>(d_out, h); sweep<OP_CNDMASK>(d_out, h); sweep<OP_MIX>(d_out, h); sweep<OP_CVTF16>(d_out, h);
     sweep<OP_ALIGNBYTE>(d_out, h); sweep<OP_CVTUB>(d_out, h);
+    sweep<OP_MULDEN>(d_out, h); sweep<OP_MULNRM>(d_out, h); sweep<OP_SUBDEN>(d_out, h); sweep<OP_PKMULDEN>(d_out, h); sweep<OP_FMADEN>(d_out, h);
     sweep<OP_DSMAX>(d_out, h); sweep<OP_DSREAD>(d_out, h); sweep<OP_DSREADU8>(d_out, h); sweep<OP_DSRMW>(d_out, h);
     masks<OP_FMA>(d_out, h); masks<OP_FLOOR>(d_out, h); masks<OP_RCP>(d_out, h); masks<OP_PKFMA>(d_out, h); masks<OP_DSREAD>(d_out, h);
     return 0;

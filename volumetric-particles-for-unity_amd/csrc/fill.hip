@@ -40,6 +40,22 @@
 #ifndef VPFX_LDS_U16
 #define VPFX_LDS_U16 0
 #endif
+#ifndef VPFX_PROBE
+#define VPFX_PROBE 0
+#endif
+#if VPFX_PROBE == 9
+// in-kernel phase timer (profiling builds only, scripts/fill_phase_profile.py): wave-cycles by phase, summed over all waves
+__device__ unsigned long long g_fill_prof[8];
+extern "C" __attribute__((visibility("default"))) int vpfx_probe_read(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_prof), sizeof(g_fill_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fill_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define VPFX_TICK(ph) do { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); prof_acc[ph] += t_now_ - prof_last; prof_last = t_now_; } while (0)
+#else
+#define VPFX_TICK(ph) do { } while (0)
+#endif
 #define VPFX_LDS_READS (VPFX_LDS_U16 ? 2 : 4)      // LDS instructions per slice (lgkmcnt bookkeeping)
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
@@ -238,13 +254,29 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
     return (unsigned)fmaf(fid, S2f * pf, fmaf(y0, pf, x0 + lds_bias));
 }
 
-template <bool EXACT, bool DONE>
+// BYTES (VPFX_BYTE_DENORM): q holds the four texel BYTES as loaded by ds_read_u8, reinterpreted as floats -- denormals b * 2^-149 (the
+// kernels run with f32 denormals enabled, hipcc's default).  Instead of four quarter-rate v_cvt_f32_u32 the bilinear works on them directly:
+// differences of denormals are exact, and the x weight and the two base texels are scaled by K = 2^126 (three full-rate v_mul_f32), so that
+// every FMA sees normal-range products: raw comes out as 2^-23 x the filtered byte with exactly the roundings of the converted form (scaling
+// by powers of two commutes with rounding; nothing under- or overflows: |K tx (b1 - b0) 2^-149| < 2^-15, smallest non-zero term >= 2^-23 ulp
+// of a weight >= 2^-24), and 2^23 is folded into Dk.  Bit-identical bricks, 10 -> 9 instructions, none of them quarter-rate.
+#ifndef VPFX_BYTE_DENORM
+#define VPFX_BYTE_DENORM 1
+#endif
+template <bool EXACT, bool DONE, bool BYTES = false>
 __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
                                            const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
                                            float d2, float opw, float& den, float& net, float Dk /* D, or D/255 for byte texels */,
                                            float smooth_c1 /* 10/3 in a VGPR: a VOP3 FMA reads one SGPR / no literal */)
 {
-    const float a = fmaf(tx, q.z - q.x, q.x), b = fmaf(tx, q.w - q.y, q.y);
+    float a, b;
+    if (BYTES) {
+        const float K = 8.507059173023462e37f;                                    // 2^126
+        const float txK = tx * K;
+        a = fmaf(txK, q.z - q.x, q.x * K); b = fmaf(txK, q.w - q.y, q.y * K);
+    } else {
+        a = fmaf(tx, q.z - q.x, q.x); b = fmaf(tx, q.w - q.y, q.y);
+    }
     const float raw = fmaf(ty, b - a, a);
     net = fmaf(Dk, raw, one_minus_D);                                             // netDisplacement   :119
     float t;
@@ -330,14 +362,17 @@ __device__ __forceinline__ void chain_publish(unsigned long long* w, float v, ui
 template <int NV, int MATH, int MODE, int TAB, bool CHAIN = false>
 __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts& f, FILL_PTR_PARAMS, const int xx, const int yy, const int px,
                                           const int py, const int lane, const unsigned lds_base, const int zz_a, const int zz_b,
-                                          const FillChain ch = FillChain{})
+                                          const FillChain ch = FillChain{}, unsigned long long* prof_acc = nullptr, unsigned long long* prof_last_p = nullptr)
 {
+#if VPFX_PROBE == 9
+    unsigned long long& prof_last = *prof_last_p;      // (profiling builds run the LDS kernel only)
+#endif
     constexpr bool EXACT = MATH == 1, DONE = MATH == 2;
     constexpr int CH = NV < 32 ? NV : 32;            // slices per register chunk
     constexpr int PIPE = TAB == 0 ? VPFX_FILL_PIPE : VPFX_FILL_PIPE_LDS;   // footprint loads in flight per wave
     static_assert(TAB == 0 || !EXACT, "the LDS (R8) path is default-math only: EXACT keeps the oracle's f32 table arithmetic");
     const float lds_bias = (float)(f.lds_pitch + 1) + (float)lds_base;
-    const float Dk = TAB == 0 ? f.D : f.D_over_255;
+    const float Dk = TAB == 0 ? f.D : (VPFX_BYTE_DENORM && !VPFX_LDS_U16) ? f.D_over_255 * 8388608.0f /* 2^23: cube_shade<BYTES> */ : f.D_over_255;
     const int LW = g.Nx * NV;
     const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
 
@@ -397,7 +432,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             // 8x8-column x CH-slice box in voxel units (conservative); survivors are then taken in list order
             // (ascending particle index = the reference's summation order) through the wave-uniform path below.
 #pragma unroll 1
-            for (int base = 0; base < n; base += 64) {
+            VPFX_TICK(0);                                                                // unit header
+            for (int base = 0; base < (VPFX_PROBE == 7 ? 0 : n); base += 64) {          // (probe 7: no particles at all)
             int pid_l = 0;
             bool near = false;
             if (base + lane < n) {
@@ -417,6 +453,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                 near = (ex * ex + ey * ey) + ez * ez <= rv * rv;
             }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(near);
+            VPFX_TICK(1);                                                                // pre-cull
 #pragma unroll 1
             while (todo) {
                 const int jl = __builtin_ctzll(todo);
@@ -447,7 +484,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     m = (w >= 32 ? 0xffffffffu : ((1u << w) - 1u)) << (lo - c0);
                 }
                 const uint32_t wm = wave_or(m);
-                if (wm == 0) continue;
+                VPFX_TICK(2);                                                            // per-particle set-up
+                if (wm == 0 || VPFX_PROBE == 5) continue;          // (probe 5: per-particle set-up only, no slice loop)
                 const int s_first = __builtin_ctz(wm), s_last = 31 - __builtin_clz(wm);
                 // Two-stage software pipeline over the slices of the range (>= 99 % of them contain a covered voxel):
                 //   stage 1: coverage test, cube addressing, footprint load ISSUED (one load per slice, every lane; lanes
@@ -462,7 +500,11 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     const float psx = fmaf(fs, Bx, Ax), psy = fmaf(fs, By, Ay), psz = fmaf(fs, Bz, Az);
                     d2 = fmaf(psz, psz, fmaf(psy, psy, psx * psx));
                     hit = d2 <= 0.25f;                                                   // Fill.shader:172,196
+#if VPFX_PROBE == 3
+                    tx = psx; ty = psy; const unsigned qi = lds_base + (unsigned)(lane * 4);
+#else
                     const unsigned qi = cube_address<EXACT, TAB, DONE>(f, psx, psy, psz, tx, ty, lds_bias);
+#endif
                     if constexpr (TAB == 0) {
                         const unsigned off = hit ? qi : 0u;                              // byte offset into the footprint table
                         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
@@ -473,8 +515,12 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                                      : "=&v"(q.a), "=&v"(q.b) : "v"(off) : "memory");
                         q.c = q.d = 0;
 #else
+#if VPFX_PROBE == 2
+                        q.a = q.b = q.c = q.d = off & 255u; asm volatile("" : "+v"(q.a), "+v"(q.b), "+v"(q.c), "+v"(q.d));
+#else
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "+1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
+#endif
 #endif
                     } else {
                         const unsigned off = hit ? qi : lds_base;
@@ -495,10 +541,16 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         if constexpr (TAB == 0) qf = make_float4(q[0], q[1], q[2], q[3]);
 #if VPFX_LDS_U16
                         else qf = make_float4((float)(q.a & 0xffu), (float)(q.b & 0xffu), (float)((q.a >> 8) & 0xffu), (float)((q.b >> 8) & 0xffu));   // v_cvt_f32_ubyte0 / 1
+#elif VPFX_BYTE_DENORM
+                        else qf = make_float4(__uint_as_float(q.a), __uint_as_float(q.b), __uint_as_float(q.c), __uint_as_float(q.d));   // the bytes as denormals
 #else
                         else qf = make_float4((float)q.a, (float)q.b, (float)q.c, (float)q.d);   // bytes 0..255; 1/255 is folded into Dk
 #endif
-                        cube_shade<EXACT, DONE>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
+#if VPFX_PROBE == 1          // what-if timing probes (wrong results): 1 = no shading, 2 = no LDS reads, 3 = no cube addressing
+                        den = tx + qf.x; net = ty + qf.y + qf.z + qf.w;
+#else
+                        cube_shade<EXACT, DONE, TAB != 0 && VPFX_BYTE_DENORM && !VPFX_LDS_U16>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
+#endif
 #if VPFX_FILL_LDS_TILE == 1
                         lds_dens[s * 64] += den;                                         // ds_read_b32, v_add_f32, ds_write_b32
                         atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));   // ds_max_i32
@@ -552,6 +604,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     if constexpr (TAB == 0) wait_vm<0>(q); else wait_lgkm<0>(q);
                     stage2(s, tx, ty, d2, hit, q);
                 }
+                VPFX_TICK(3);                                                            // covered-slice loop
             }
             }
 
@@ -560,6 +613,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                 if (ord > 0) prop = chain_wait(ch.words + lmi, ch.tag_base + (uint32_t)ord + ch.wait_bias, ch.error, ch.spin_limit);
                 T = (zz == 0) ? f.init_light : prop;                                     // :224
                 prop = T;
+                VPFX_TICK(4);                                                            // chain wait
             }
             // propagate + store this chunk                                               Fill.shader:231-269
             // volumeTex[int3(xy, slice)]: RGBA16F, or -- grey ambient: r = g = b bit for bit -- the z-pair entry (luminance | density)(z), (z + 1).
@@ -592,7 +646,9 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                     T *= 1.0f / (1.0f + dens[s]);                                        // rcp(1 + density) :244
                 }
             };
-            if (MODE == 0 && f.grey) propagate_store(std::true_type{}); else propagate_store(std::false_type{});
+            if (VPFX_PROBE == 6) { if (dens[lane & 31] == 123.f) brick[0] = make_uint2(0, 0); }      // (probe 6: no propagate + store)
+            else if (MODE == 0 && f.grey) propagate_store(std::true_type{}); else propagate_store(std::false_type{});
+            VPFX_TICK(5);                                                                // propagate + store
         }
         if (CHAIN) {
             // the column's last occupied metavoxel writes the light map (every other value of the column is only ever seen by the next unit)
@@ -654,6 +710,11 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
     const unsigned lds_base = (unsigned)(size_t)lds_cube;       // low half of the flat address of an LDS object = its LDS byte offset
     constexpr int T8 = NV / 8, TPC = T8 * T8;                    // 8x8-column tiles per MV column
     const int lane = threadIdx.x & 63;
+#if VPFX_PROBE == 9
+    unsigned long long prof_acc[8] = {};
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long prof_last = prof_t0;
+#endif
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(p_counter, 1);
@@ -666,8 +727,18 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
         const int nxy = g.Nx * g.Ny, zz = mi / nxy, col = mi - zz * nxy;
         const int xx = col % g.Nx, yy = col / g.Nx;
         fill_tile<NV, DONE ? 2 : 0, MODE, TAB, true>(g, f, p_mvPos, p_offsets, p_ids, p_rec, p_brick_index, p_colorder, p_cubequads, p_depthmap,
-                                              p_light_in, p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, zz, zz + 1, ch);
+                                              p_light_in, p_light_out, p_bricks, p_dens_ao, p_ws, xx, yy, px, py, lane, lds_base, zz, zz + 1, ch
+#if VPFX_PROBE == 9
+                                              , prof_acc, &prof_last);
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_acc[6] += t - prof_last; prof_last = t; }   // publish + tail of the unit
+#else
+                                              );
+#endif
     }
+#if VPFX_PROBE == 9
+    prof_acc[7] = __builtin_amdgcn_s_memtime() - prof_t0;
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_fill_prof[i], prof_acc[i]);
+#endif
 }
 
 // Second half of the split (multi-GPU) fill: stream density/ao back, propagate with the true incoming light.
