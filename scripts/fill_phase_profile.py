@@ -6,8 +6,11 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 lib_path = sys.argv[1]
 pkg = os.path.join(root, "volumetric-particles-for-unity_amd")
+def swap_in(src):          # rename, never overwrite: a loaded library's mapping must keep its inode
+    shutil.copy(src, os.path.join(pkg, "libvpfx.so.new"))
+    os.replace(os.path.join(pkg, "libvpfx.so.new"), os.path.join(pkg, "libvpfx.so"))
 shutil.copy(os.path.join(pkg, "libvpfx.so"), "/tmp/libvpfx_keep.so")
-shutil.copy(lib_path, os.path.join(pkg, "libvpfx.so"))
+swap_in(lib_path)
 try:
     from __graft_entry__ import load_package
     load_package()
@@ -41,4 +44,4 @@ try:
     print(f"  {'(sum of phases / wave lifetime)':58s} {100 * sum(v[:7]) / tot:5.1f} %")
     e.close()
 finally:
-    shutil.copy("/tmp/libvpfx_keep.so", os.path.join(pkg, "libvpfx.so"))
+    swap_in("/tmp/libvpfx_keep.so")
