@@ -294,7 +294,7 @@ typedef struct vp_multi_info {
     int32_t chain[VP_MAX_RANKS];  /* ranks front to back as the last vp_raymarch composited them                               */
     int32_t group_of[VP_MAX_RANKS];        /* hand-off group of every rank in that frame                                       */
     int64_t samples[VP_MAX_RANKS];         /* lattice samples executed per LOCAL rank in the last vp_raymarch (0 for remote ones) */
-    float   stage_ms[VP_MAX_RANKS][4];     /* per LOCAL rank: bin, fill (local pass), ray-march, fill finish kernel times       */
+    float   stage_ms[VP_MAX_RANKS][4];     /* per LOCAL rank: bin, fill (local pass; rank 0: its fused fill), ray-march, fill finish kernel times (rank 0: none) */
     float   exchange_ms[4];       /* rank-0-of-this-process stream time: tau all-gather, saturation hand-off, image exchange + blend, - */
 } vp_multi_info;
 int  vp_get_multi_info(vp_ctx* ctx, vp_multi_info* out);
@@ -306,8 +306,10 @@ int  vp_rebalance(vp_ctx* ctx);
 /* 128 bytes identifying a new RCCL communicator (ncclGetUniqueId): call on ONE process, hand the bytes to every process of the job
  * (any transport: MPI, a TCP store, a file) and pass them in vp_config.rccl_unique_id. */
 int  vp_rccl_unique_id(uint8_t out[128]);
-/* The slab cut itself (host-only, no GPU needed): fill_ms[z], rm_ms[z] = estimated milliseconds per light-axis slice; the frame waits for
- * the slowest slab in the fill and, per hand-off group, in the ray-march.  cuts_out[world + 1]. */
+/* The slab cut itself (host-only, no GPU needed): fill_ms[z] (the fill's local pass), rm_ms[z] = estimated milliseconds per light-axis
+ * slice.  The frame waits for the slowest slab in the local pass (it ends in the all-gather of the transmittance maps) and then for the
+ * slowest slab's finish pass (0.42 x its local pass; not the slab nearest the light, whose fill is fused) + ray-march (per hand-off group
+ * when rm_groups > 1).  cuts_out[world + 1]. */
 int  vp_plan_slabs(int32_t nz, int32_t world, const double* fill_ms, const double* rm_ms, int32_t rm_groups, int32_t* cuts_out);
 /* Front-to-back compositing order of the slabs for a given zBoundary (VPR.cs:652-711 at slab granularity) and the blend plan of their
  * partial images: chain_out[world] = ranks front to back (the slab straddling zBoundary first, then the phase-A slabs zz descending, then

@@ -8,8 +8,10 @@ For every (N, hand-off groups):
      the device and stretch each other), with the same cut, the same kernels and the real hand-off maps of the slabs in front
      (vp_raymarch_partial_handoff_device), front to back along the chain;
   3. the per-rank kernel times are combined as the pipeline does:
+        t_N = max_r(bin_r + fill_local_r) + t(tau all-gather) + max_r(finish_r + raymarch_r) + t(image exchange) + t(blend)      [one group]
         t_N = max_r(bin_r + fill_local_r) + t(tau all-gather) + max_r(finish_r)
             + sum over hand-off groups g of max_{r in g}(raymarch_r) + (groups - 1) * t(hand-off hop) + t(image exchange) + t(blend)
+     (slab 0, nearest the light, runs the fused fill: fill_local_0 = its fused kernel, finish_0 = 0)
 The exchange terms are xGMI ESTIMATES (one link ~50 GB/s usable per direction, seven links per GPU, ~40 us software latency per RCCL call),
 stated in the output; everything else is measured.  The host side is the library's worker threads (one per GPU), not modelled: each
 issues ~25 launches per frame.  usage: scaling_model.py [C3] [r8|f32]"""
@@ -82,13 +84,15 @@ for world in (2, 4, 8):
             over, under = torch.empty_like(img), torch.empty_like(img)
             t_out = torch.empty((2, sc.height, sc.width), device=dev, dtype=torch.uint8)
             for _ in range(3):
-                e.bin_resident(); e.fill_local(sc.fill_params(), tau_all[r].data_ptr()); e.fill_finish_gathered(tau_all.data_ptr(), r, world)
+                e.bin_resident()
+                if r == 0: e.fill(sc.fill_params())          # the slab nearest the light: fused fill, no finish pass (multi.cpp: multi_fill)
+                else: e.fill_local(sc.fill_params(), tau_all[r].data_ptr()); e.fill_finish_gathered(tau_all.data_ptr(), r, world)
                 e.raymarch_partial_handoff_device(cam, rp, over.data_ptr(), under.data_ptr(), t_in.data_ptr() if front else 0, len(front),
                                                   t_out[0].data_ptr(), t_out[1].data_ptr())
             e.sync()
             st = e.stats()
             maps[r] = (t_out[0].clone(), t_out[1].clone())
-            rows[r] = dict(slab=[cuts[r], cuts[r + 1]], group=group_of[r], bin=e.last_kernel_ms(0), fill_local=e.last_kernel_ms(1), finish=e.last_kernel_ms(3),
+            rows[r] = dict(slab=[cuts[r], cuts[r + 1]], group=group_of[r], bin=e.last_kernel_ms(0), fill_local=e.last_kernel_ms(1), finish=e.last_kernel_ms(3) if r else 0.0,
                            rm=e.last_kernel_ms(2), samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"])
             e.close(); del tau_all, over, under
             torch.cuda.empty_cache()
@@ -100,8 +104,11 @@ for world in (2, 4, 8):
         t_blend = 0.02e-3
         G = max(group_of) + 1
         rm_groups = [max(rows[r]["rm"] for r in chain if group_of[r] == g) for g in range(G)]
-        t = (max(x["bin"] + x["fill_local"] for x in rows.values()) + max(x["finish"] for x in rows.values()) + sum(rm_groups)) * 1e-3 \
-            + t_tau + (G - 1) * t_hop + t_img + t_blend
+        if G == 1:      # after the tau all-gather every slab runs its finish pass (not slab 0) and its ray-march back to back; the image exchange waits for the slowest
+            after = max(x["finish"] + x["rm"] for x in rows.values())
+        else:
+            after = max(x["finish"] for x in rows.values()) + sum(rm_groups)
+        t = (max(x["bin"] + x["fill_local"] for x in rows.values()) + after) * 1e-3 + t_tau + (G - 1) * t_hop + t_img + t_blend
         key = f"{world}gpu_{groups}groups"
         out["predictions"][key] = {
             "world": world, "rm_groups": groups, "slab_cuts": cuts, "chain": chain, "group_of": group_of, "per_rank": [rows[r] for r in range(world)],
@@ -109,7 +116,7 @@ for world in (2, 4, 8):
             "raymarch_ms_per_group": rm_groups, "predicted_ms_per_step": t * 1e3, "speedup_vs_1gpu": one_ms / (t * 1e3),
             "samples_executed_all_ranks": sum(x["samples"] for x in rows.values())}
         print(f"N={world} groups={groups}: predicted {t * 1e3:.2f} ms/step ({one_ms / (t * 1e3):.2f}x); cut {cuts}; "
-              f"max bin+fill_local {max(x['bin'] + x['fill_local'] for x in rows.values()):.2f} finish {max(x['finish'] for x in rows.values()):.2f} "
+              f"max bin+fill_local {max(x['bin'] + x['fill_local'] for x in rows.values()):.2f} finish {max(x['finish'] for x in rows.values()):.2f} max finish+rm {max(x['finish'] + x['rm'] for x in rows.values()):.2f} "
               f"rm per group {[round(x, 3) for x in rm_groups]} (max single {max(x['rm'] for x in rows.values()):.3f}); exchanges {1e3 * (t_tau + (G - 1) * t_hop + t_img):.2f}; "
               f"samples {sum(x['samples'] for x in rows.values()) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M; fan-out image err {err:.1e}", flush=True)
 os.makedirs("gpurun_out/r3", exist_ok=True)

@@ -57,10 +57,14 @@ def test_fanout_matches_single_context_and_oracle(world, flags):
         a = single.read_brick(xx[i], yy[i], zz[i]).view(np.uint16).astype(np.int32)
         b = m.read_brick(xx[i], yy[i], zz[i]).view(np.uint16).astype(np.int32)
         assert np.abs(a - b).max() <= 1                      # T_in = product of the nearer slabs' maps: reassociated, <= 1 fp16 ulp
+        if zz[i] < cuts[1]:
+            assert np.array_equal(a, b)                      # rank 0 (nearest the light) runs the fused single-GPU fill: the same bits
         assert np.array_equal(m.bin_list(xx[i], yy[i], zz[i]), single.bin_list(xx[i], yy[i], zz[i]))
     st, s1 = m.stats(), single.stats()
     for key in ("particles", "occupied_mv", "pairs", "voxels_filled"):
         assert st[key] == s1[key], key
+    ms = info["stage_ms"]
+    assert ms[0][1] > 0 and ms[0][3] == 0 and all(ms[r][3] > 0 for r in range(1, world))    # no finish pass on rank 0, one on every other
     # a second frame on the same context: other camera (straddling zBoundary), rebalanced slabs
     sc.set_camera((2.0, 1.0, -1.5))
     cam, rp = sc.camera(), sc.raymarch_params()

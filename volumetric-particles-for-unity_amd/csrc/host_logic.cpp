@@ -249,10 +249,15 @@ void min_max_partition(int nz, int world, const std::vector<double>& w, int* cut
     for (int k = world; k >= 1; --k) { z = arg[k][z]; cuts[k - 1] = z; }
 }
 
-// Exact optimum of  W * max_r F_r + max_r R_r  over contiguous partitions into `world` slabs of >= 1 slice (F, R = per-slice costs of two
-// pipeline stages that each wait for their slowest slab): for every candidate bound B on the first maximum (all interval sums of F), a
-// min-max DP of R over the partitions whose slabs all keep F <= B; the best B wins.  nz^2 / 2 bounds x world x nz^2 steps: ~4 M at nz = 32.
-double two_maxima_partition(int nz, int world, const std::vector<double>& F, const std::vector<double>& R, double W, int* cuts)
+// The finish pass of the split fill (stream (density, ao) back, store the bricks) as a share of the slab's local pass: 0.75 / 1.72, 0.38 / 0.94,
+// 0.29 / 0.60 ms at 2 / 4 / 8 slabs of C3 (profiles/r03_scaling_model_C3_r8.txt).
+#define VPFX_FINISH_SHARE 0.42
+// Exact optimum of  max_r F_r + max_r (C F_r [r > 0] + R_r)  over contiguous partitions into `world` slabs of >= 1 slice: F = per-slice cost
+// of the fill's local pass, which ends in a collective (every slab waits for the slowest); after it a slab runs its finish pass (C F; not the
+// first slab, whose fill is fused) and its ray-march (R) back to back, and the image exchange waits for the slowest of THOSE.  For every
+// candidate bound B on the first maximum (all interval sums of F), a min-max DP of the second term over the partitions whose slabs all keep
+// F <= B; the best B wins.  nz^2 / 2 bounds x world x nz^2 steps: ~4 M at nz = 32.
+double two_maxima_partition(int nz, int world, const std::vector<double>& F, const std::vector<double>& R, double C, int* cuts)
 {
     std::vector<double> pf(nz + 1, 0.0), pr(nz + 1, 0.0);
     for (int z = 0; z < nz; ++z) { pf[z + 1] = pf[z] + std::max(F[z], 0.0); pr[z + 1] = pr[z] + std::max(R[z], 0.0); }
@@ -267,14 +272,14 @@ double two_maxima_partition(int nz, int world, const std::vector<double>& F, con
     std::vector<std::vector<int>> arg(world + 1, std::vector<int>(nz + 1));
     std::vector<int> cand(world + 1);
     for (double B : bounds) {
-        if (W * B >= best) break;                            // bounds ascend: no later one can win
+        if (B >= best) break;                                // bounds ascend: no later one can win
         for (auto& row : dp) std::fill(row.begin(), row.end(), INF);
         dp[0][0] = 0.0;
         for (int k = 1; k <= world; ++k)
             for (int z = k; z <= nz - (world - k); ++z)
                 for (int y = k - 1; y < z; ++y) {
                     if (dp[k - 1][y] >= INF || pf[z] - pf[y] > B) continue;
-                    const double v = std::max(dp[k - 1][y], pr[z] - pr[y]);
+                    const double v = std::max(dp[k - 1][y], (pr[z] - pr[y]) + (k > 1 ? C * (pf[z] - pf[y]) : 0.0));   // k == 1: the fused first slab has no finish pass
                     if (v < dp[k][z]) { dp[k][z] = v; arg[k][z] = y; }
                 }
         if (dp[world][nz] >= INF) continue;
@@ -283,7 +288,7 @@ double two_maxima_partition(int nz, int world, const std::vector<double>& F, con
         for (int k = world; k >= 1; --k) { z = arg[k][z]; cand[k - 1] = z; }
         double fmax = 0.0;
         for (int r = 0; r < world; ++r) fmax = std::max(fmax, pf[cand[r + 1]] - pf[cand[r]]);
-        const double t = W * fmax + dp[world][nz];
+        const double t = fmax + dp[world][nz];
         if (t < best - 1e-12) { best = t; for (int i = 0; i <= world; ++i) cuts[i] = cand[i]; }
     }
     return best;
@@ -297,10 +302,11 @@ void hl_chain_groups(int world, int rm_groups, int* group_of_pos)
     for (int p = 0; p < world; ++p) group_of_pos[p] = (int)(((long long)p * G) / world);
 }
 
-// The frame waits for the slowest slab in the fill (x 1.3: local pass + finish pass of the split fill) and, in the ray-march, for the
-// slowest slab of every hand-off group in turn (groups run one after the other; within a group the slabs march concurrently).  The cut
-// that balances fill + ray-march per slice need not minimise that.  Without a hand-off (one group) the modelled frame is a sum of two
-// maxima, minimised exactly (two_maxima_partition).  With groups the candidates are that cut and the optimal min-max partitions of
+// The frame waits for the slowest slab in the fill's local pass (it ends in the all-gather of the transmittance maps), then every slab runs
+// its finish pass (not the first one: fused fill) and its ray-march, and the image exchange waits for the slowest of those; with hand-off
+// groups the ray-march waits for the slowest slab of every group in turn (groups run one after the other; within a group the slabs march
+// concurrently).  The cut that balances fill + ray-march per slice need not minimise that.  Without a hand-off (one group) the modelled
+// frame is a sum of two maxima, minimised exactly (two_maxima_partition).  With groups the candidates are that cut and the optimal min-max partitions of
 // fill + alpha * raymarch for a few alpha (0 = fill only ... raymarch only), and the one with the smallest modelled frame wins (ties: the
 // earliest candidate).  Groups are taken in rank order here (exact for a camera outside the grid along the light axis, the benchmark's
 // case; a camera inside the grid reorders the chain around the straddling slab).
@@ -319,21 +325,25 @@ void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms
     for (int z = 0; z < nz; ++z) { Fv[z] = fill_ms ? fill_ms[z] : 0.0; Rv[z] = rm_ms ? rm_ms[z] : 0.0; }
     for (double a : alphas) {
         if (a == -2.0) {
-            (void)two_maxima_partition(nz, world, Fv, Rv, 1.3, cand.data());         // the exact optimum for one group
+            (void)two_maxima_partition(nz, world, Fv, Rv, VPFX_FINISH_SHARE, cand.data());   // the exact optimum for one group
         } else {
             for (int z = 0; z < nz; ++z) w[z] = a < 0.0 ? Rv[z] : Fv[z] + a * Rv[z];
             min_max_partition(nz, world, w, cand.data());
         }
-        double fmax = 0.0;
+        double fmax = 0.0, finmax = 0.0, onemax = 0.0;
         std::vector<double> gmax(world, 0.0);
         for (int r = 0; r < world; ++r) {
             double f = 0.0, m = 0.0;
             for (int z = cand[r]; z < cand[r + 1]; ++z) { f += fill_ms ? fill_ms[z] : 0.0; m += rm_ms ? rm_ms[z] : 0.0; }
+            const double fin = r > 0 ? VPFX_FINISH_SHARE * f : 0.0;          // the fused first slab has no finish pass
             fmax = std::max(fmax, f);
+            finmax = std::max(finmax, fin);
+            onemax = std::max(onemax, fin + m);
             gmax[gp[r]] = std::max(gmax[gp[r]], m);
         }
-        double t = 1.3 * fmax;
-        for (double g : gmax) t += g;
+        double t = fmax;
+        if (gp[world - 1] == 0) t += onemax;                          // one group: finish and ray-march of a slab run back to back
+        else { t += finmax; for (double g : gmax) t += g; }           // chained groups (conservative: every finish before the first group)
         if (!have || t < best_t - 1e-12) { best_t = t; have = true; for (int i = 0; i <= world; ++i) cuts[i] = cand[i]; }
     }
 }
