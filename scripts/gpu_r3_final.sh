@@ -2,6 +2,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3f
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 > gpurun_out/r3f/tests.log; grep -E "passed|failed" gpurun_out/r3f/tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -1
 timeout 900 python bench.py 2> gpurun_out/r3f/bench_default.err | tail -1 > gpurun_out/r3f/bench_C3_r8_default.json
 timeout 600 python bench.py --no-cpu-baseline --displacement-scale 1.0 2>/dev/null | tail -1 > gpurun_out/r3f/bench_C3_r8_D1.json
 timeout 600 python bench.py --no-cpu-baseline --cubemap f32 2>/dev/null | tail -1 > gpurun_out/r3f/bench_C3_f32.json

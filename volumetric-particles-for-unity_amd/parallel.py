@@ -95,7 +95,9 @@ def choose_slabs(nz: int, world: int, fill_ms: Sequence[float], rm_ms: Sequence[
     """Slab cut for the two-stage pipeline.  The stages are separated by collectives, so a frame costs
     max_r(fill_r) * 1.3 (local + finish pass) + max_r(raymarch_r): the cut that balances the SUM per slice need not minimise
     that.  Candidates = optimal contiguous partitions of fill + alpha * raymarch for a few alpha (0 = fill only ... inf = ray-march
-    only); the one with the smallest stage-maxima sum wins (ties: the earliest candidate, i.e. the more fill-balanced)."""
+    only); the one with the smallest stage-maxima sum wins (ties: the earliest candidate, i.e. the more fill-balanced).
+    (This pipeline runs the split fill on every rank, so it keeps this model; the library's fan-out -- csrc/multi.cpp, hl_plan_slabs --
+    runs the fused fill on rank 0 and minimises  max_r F_r + max_r (0.42 F_r [r > 0] + R_r)  exactly.)"""
     best, best_t = None, float("inf")
     for alpha in (0.0, 0.25, 0.5, 1.0, 2.0, 4.0, None):
         w = [r if alpha is None else f + alpha * r for f, r in zip(fill_ms, rm_ms)]
