@@ -578,15 +578,18 @@ int multi_fill(vp_ctx* P, const vp_fill_params* p)
         // ray-march (light and camera on the same side, the benchmark's case), which it can now start while the others finish.
         const bool fused = k.rank == 0;
         int r;
+        c->filled = false;
         if (fused) {
-            r = launch_fill(c, 0, nullptr, c->d_lightmap); if (r) return r;
-            VP_HIP(hipMemcpyAsync(k.d_tau_all, c->d_lightmap, M->lm * sizeof(float), hipMemcpyDeviceToDevice, k.stream));
-            c->local_done = false; c->filled = false; c->ev_valid[3] = false;
+            r = launch_fill(c, 0, nullptr, c->d_lightmap);
+            if (!r && hipMemcpyAsync(k.d_tau_all, c->d_lightmap, M->lm * sizeof(float), hipMemcpyDeviceToDevice, k.stream) != hipSuccess)
+                r = vp_fail(c, VP_ERR_HIP, "hipMemcpyAsync (transmittance map) failed");
+            c->local_done = false; c->ev_valid[3] = false;
         } else {
             // slab-local pass (T_in = 1): density / ao to scratch, the slab's transmittance map straight into its slot of the gather buffer
-            r = launch_fill(c, 1, nullptr, k.d_tau_all + (size_t)k.rank * M->lm); if (r) return r;
-            c->local_done = true; c->filled = false;
+            r = launch_fill(c, 1, nullptr, k.d_tau_all + (size_t)k.rank * M->lm);
+            c->local_done = r == VP_OK;
         }
+        VP_VOTE(r);                                             // a rank whose launch failed must not leave the others inside the all-gather
         VP_HIP(hipEventRecord(k.ev[0][0], k.stream));
         r = all_gather_inplace(M, k, k.d_tau_all, M->lm); if (r) return r;
         VP_HIP(hipEventRecord(k.ev[0][1], k.stream));
@@ -650,7 +653,7 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         hipError_t he = hipMemsetAsync(c->d_zsamples, 0, (size_t)VPFX_ZPROF_COPIES * c->g.Nz * sizeof(unsigned), k.stream);
         r = he == hipSuccess ? launch_raymarch(c, kc, k.d_img[0], k.d_img[1], &ho) : vp_fail(c, VP_ERR_HIP, "hipMemsetAsync failed");
         c->d_scene_depth = keep;
-        if (r) return r;
+        if (r) return r;       // (no vote here: with hand-off groups the later groups are still waiting for this rank's maps, step (3))
         // (3) hand-off out: a phase-A-only slab behind this one is hidden by this slab's phase-A image only (t_out0), every other by both
         ops.clear();
         for (int p = my_pos + 1; p < world; ++p) {
