@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL shares device buffers between the ranks' processes through IPC handles; this pool's host driver supports dmabuf IPC only
+# (without it: hipIpcGetMemHandle: invalid argument).  Read by the HSA runtime when it starts, i.e. before the first HIP call below.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
