@@ -26,7 +26,7 @@ try:
     for _ in range(3):
         e.fill(sc.fill_params())
     e.sync()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 12)()
     assert lib.vpfx_probe_read(buf, 1) == 0
     reps = 5
     for _ in range(reps):
@@ -42,6 +42,9 @@ try:
     for n, x in zip(names, v[:7]):
         print(f"  {n:58s} {100 * x / tot:5.1f} %")
     print(f"  {'(sum of phases / wave lifetime)':58s} {100 * sum(v[:7]) / tot:5.1f} %")
+    if v[8]:
+        print(f"  units with a producer in their column {v[8]:.0f}; {100 * v[9] / v[8]:.1f} % of them found the hand-off word missing at the first look and "
+              f"polled again, {v[10] / max(v[9], 1):.1f} more polls each on average")
     e.close()
 finally:
     swap_in("/tmp/libvpfx_keep.so")

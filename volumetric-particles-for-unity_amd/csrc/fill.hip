@@ -45,11 +45,11 @@
 #endif
 #if VPFX_PROBE == 9
 // in-kernel phase timer (profiling builds only, scripts/fill_phase_profile.py): wave-cycles by phase, summed over all waves
-__device__ unsigned long long g_fill_prof[8];
+__device__ unsigned long long g_fill_prof[12];    // [0..6] wave-cycles by phase, [7] wave lifetime, [8] units with a producer, [9] of which had to poll again, [10] polls
 extern "C" __attribute__((visibility("default"))) int vpfx_probe_read(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_prof), sizeof(g_fill_prof)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fill_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[12] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fill_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #define VPFX_TICK(ph) do { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); prof_acc[ph] += t_now_ - prof_last; prof_last = t_now_; } while (0)
@@ -333,14 +333,16 @@ struct FillChain {
     uint32_t wait_bias;           // 0; the test hook adds an offset to the awaited tag so that it never arrives
 };
 #define VPFX_CHAIN_SPIN_LIMIT (1u << 22)       // x (s_sleep 8 = 512 cycles + a memory round trip): seconds; a real wait is microseconds
-__device__ __forceinline__ float chain_wait(const unsigned long long* w, uint32_t tag, int* error, uint32_t spin_limit)
+__device__ __forceinline__ float chain_wait(const unsigned long long* w, uint32_t tag, int* error, uint32_t spin_limit, unsigned* polls = nullptr)
 {
     unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (unsigned spins = 0; (uint32_t)(v >> 32) != tag; ++spins) {
+    unsigned spins = 0;
+    for (; (uint32_t)(v >> 32) != tag; ++spins) {
         if (spins > spin_limit) { *error = 1; break; }        // never seen; reported at the caller's next sync instead of hanging the GPU
         __builtin_amdgcn_s_sleep(8);
         v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (polls) *polls = spins;                                // (profiling builds)
     return __uint_as_float((uint32_t)v);
 }
 __device__ __forceinline__ void chain_publish(unsigned long long* w, float v, uint32_t tag)
@@ -610,7 +612,18 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 
             if (CHAIN && c0 == 0) {
                 // the light that reaches this metavoxel: what the column's previous occupied metavoxel handed on (its unit was claimed earlier)
+#if VPFX_PROBE == 9
+                if (ord > 0) {
+                    unsigned polls = 0;
+                    prop = chain_wait(ch.words + lmi, ch.tag_base + (uint32_t)ord + ch.wait_bias, ch.error, ch.spin_limit, &polls);
+                    const unsigned long long again = __builtin_amdgcn_ballot_w64(polls > 0);
+                    unsigned mx = polls;
+                    for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+                    prof_acc[8] += 1; prof_acc[9] += again != 0; prof_acc[10] += mx;
+                }
+#else
                 if (ord > 0) prop = chain_wait(ch.words + lmi, ch.tag_base + (uint32_t)ord + ch.wait_bias, ch.error, ch.spin_limit);
+#endif
                 T = (zz == 0) ? f.init_light : prop;                                     // :224
                 prop = T;
                 VPFX_TICK(4);                                                            // chain wait
@@ -711,7 +724,7 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
     constexpr int T8 = NV / 8, TPC = T8 * T8;                    // 8x8-column tiles per MV column
     const int lane = threadIdx.x & 63;
 #if VPFX_PROBE == 9
-    unsigned long long prof_acc[8] = {};
+    unsigned long long prof_acc[12] = {};
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long prof_last = prof_t0;
 #endif
@@ -737,7 +750,7 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
     }
 #if VPFX_PROBE == 9
     prof_acc[7] = __builtin_amdgcn_s_memtime() - prof_t0;
-    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_fill_prof[i], prof_acc[i]);
+    if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_fill_prof[i], prof_acc[i]);
 #endif
 }
 
