@@ -315,3 +315,39 @@ def test_fanout_many_frames_with_recuts_is_stable_and_deterministic():
                 first[key] = img.copy()
         m.close()
     single.close()
+
+
+@pytest.mark.parametrize("case", ["no_particles", "empty_front_slabs", "one_slice_per_rank", "float_cubemap_exact"])
+def test_fanout_edge_cases_match_the_single_context(case):
+    """Degenerate slabs through the fan-out: nothing to fill at all, a rank 0 (fused fill) without an occupied metavoxel, as many ranks as
+    light-axis slices, and the float-table EXACT kernels (rank 0 fused, the others split)."""
+    sc = S.make_scene("C1", cubemap="f32" if case == "float_cubemap_exact" else "r8")
+    world, kw = 4, {}
+    if case == "no_particles":
+        sc.particles = sc.particles[:0].copy()
+    elif case == "empty_front_slabs":
+        # keep only particles in the half of the grid away from the light: ranks cut from the pair histogram still get slabs in front of them
+        L = np.asarray(sc.light_to_world, dtype=np.float64).reshape(4, 4).T            # column-major 16 floats -> matrix
+        ls_z = (np.asarray(sc.particles["position"], dtype=np.float64) - L[:3, 3]) @ L[:3, 2]   # light-space depth (psys transform = identity at C1)
+        sc.particles = sc.particles[ls_z > np.median(ls_z)].copy()
+        kw["flags"] = abi.VP_MULTI_UNIFORM_SLABS
+    elif case == "one_slice_per_rank":
+        world = sc.N[2]
+    exact = case == "float_cubemap_exact"
+    single, ref = _single(sc, exact=exact)
+    m = _fanout(sc, world, kw.get("flags", 0), exact=exact)
+    img = _frame(m, sc)
+    assert np.abs(img - ref).max() <= 2e-5
+    assert np.array_equal(m.bin_counts(), single.bin_counts())
+    np.testing.assert_allclose(m.read_lightmap(), single.read_lightmap(), rtol=2e-5, atol=1e-9)
+    info = m.multi_info()
+    assert info["slab_cuts"][0] == 0 and info["slab_cuts"][-1] == sc.N[2] and len(info["slab_cuts"]) == world + 1
+    if case == "empty_front_slabs":
+        cnt = single.bin_counts()
+        assert cnt[: info["slab_cuts"][1]].sum() == 0, "rank 0's slab was meant to be empty"
+    if case == "no_particles":
+        assert not img.any()
+    # a second frame: the contexts survive a refill
+    m.bin_resident(); m.fill(sc.fill_params())
+    assert np.abs(m.raymarch(sc.camera(), sc.raymarch_params()) - ref).max() <= 2e-5
+    m.close(); single.close()
