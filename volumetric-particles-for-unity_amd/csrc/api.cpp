@@ -307,7 +307,7 @@ void vp_destroy_single(vp_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
-                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo};
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo, c->d_occmask};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);

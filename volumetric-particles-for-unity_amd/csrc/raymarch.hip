@@ -48,6 +48,34 @@ VPFX_MIX_FMA(mix_fma_lo, 0)
 VPFX_MIX_FMA(mix_fma_hi, 1)
 
 
+#ifndef VPFX_RM_PROBE
+#define VPFX_RM_PROBE 0
+#endif
+#if VPFX_RM_PROBE == 9
+// in-kernel phase timer of k_raymarch (profiling builds only, scripts/raymarch_phase_profile.py): wave-cycles by phase, all waves, 64 replicated rows
+__device__ unsigned long long g_rm_prof[64][8];
+extern "C" __attribute__((visibility("default"))) int vpfx_rm_probe_read(unsigned long long* out, int reset)
+{
+    static unsigned long long h[64][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rm_prof), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) { out[i] = 0; for (int r = 0; r < 64; ++r) out[i] += h[r][i]; }
+    if (reset) { for (auto& row : h) for (auto& x : row) x = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rm_prof), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
+#define VPFX_RM_TICK(ph) do { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); rm_prof[ph] += t_now_ - rm_last; rm_last = t_now_; } while (0)
+#define VPFX_RM_PROF_ARGS , unsigned long long* rm_prof, unsigned long long& rm_last
+#define VPFX_RM_PROF_PASS , rm_prof, rm_last
+#define VPFX_RM_PROF_DUMMY unsigned long long rm_prof[8] = {}; unsigned long long rm_last = 0;
+#else
+#define VPFX_RM_TICK(ph) do { } while (0)
+#define VPFX_RM_PROF_ARGS
+#define VPFX_RM_PROF_PASS
+#define VPFX_RM_PROF_DUMMY
+#endif
+#ifndef VPFX_RM_OCC_LDS
+#define VPFX_RM_OCC_LDS 1       // occupancy bitmask of the grid in LDS for the cell walk (k_raymarch); 0 = A/B
+#endif
+#define VPFX_RM_OCC_WORDS 1024  // Nz * Ny <= 1024 and Nx <= 32 (C1 .. C4); larger grids walk on the per-cell records alone
 #ifndef VPFX_RM_CELLINFO
 #define VPFX_RM_CELLINFO 1      // per-cell (translation, brick slot) records for the streaming cell walk (see k_raymarch): 0.967 -> 0.951 ms at C3; 0 = A/B
 #endif
@@ -145,7 +173,7 @@ __device__ __forceinline__ RayCtx ray_setup(const RmConsts& k, int col, int row,
 // channels to filter.  Same image bit for bit as RGBA16F bricks.
 template <int NV, bool WRAP, bool FLAGS, bool GREY>
 __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, const uint2* __restrict__ brick, const float4 tr,
-                                         F4& src, int& nsamp)
+                                         F4& src, int& nsamp VPFX_RM_PROF_ARGS)
 {
     static_assert(!(WRAP && GREY), "grey bricks are only used with border >= 1 (the footprint never wraps)");
     const float ox = R.lx + tr.x, oy = R.ly + tr.y, oz = R.lz + tr.z;                     // mvRay.o :216
@@ -257,6 +285,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     const int tSoft = max(tEntry, min(tExit + 1, tCamera + k.soft));
     int si = tExit;
     float fsi = (float)si;                              // the index as a float, stepped with adds (one conversion per metavoxel, not per sample)
+    VPFX_RM_TICK(2);                                    // per-metavoxel set-up (box test, lattice range, texel lattice)
     // (Measured and dropped: issuing the next two samples' eight loads before filtering the current two -- two register sets, 8-16 loads
     // in flight per wave -- 1.49 vs 1.48 ms: loads in flight per wave are not what limits the kernel.)
     // (Grey bricks, measured: four samples per iteration -- 8 loads in flight -- 1.02 ms at 4 waves/SIMD against 1.09 for two, but the
@@ -303,6 +332,7 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
         const int dc = si - tCamera;
         blend(c, dc < k.soft ? c.w * ((float)dc * k.inv_soft) : c.w);
     }
+    VPFX_RM_TICK(3);                                    // the sample loops
     const int ns = max(0, tExit - tEntry + 1);
     nsamp += ns;
     if (GREY) { rg = rr; rb = rr; }
@@ -329,7 +359,8 @@ __device__ __forceinline__ F4 draw_order_color(int order_index, int num_covered)
 // (VPR.cs:774-778), same operation order as the matrix product the reference does per draw.
 __global__ void __launch_bounds__(256)
 k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict__ mvPos, int n, float4* __restrict__ out,
-           float4* __restrict__ cellinfo /* nullable: [N^3] records (translation, brick slot), preset to -1 */)
+           float4* __restrict__ cellinfo /* nullable: [N^3] records (translation, brick slot), preset to -1 */,
+           uint32_t* __restrict__ occmask /* nullable: [Nz][Ny] occupancy bits, preset to 0 */)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -344,6 +375,7 @@ k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict
     }
     out[i] = make_float4(tr[0], tr[1], tr[2], 0.f);
     if (cellinfo) cellinfo[mi] = make_float4(tr[0], tr[1], tr[2], __int_as_float(i));
+    if (occmask) atomicOr(&occmask[mi / k.Nx], 1u << (mi % k.Nx));             // mi = (zz Ny + yy) Nx + xx
 }
 
 // Dispatch order of the screen super-tiles (64x32 px): most expensive first, so that the long rays are not what the
@@ -447,7 +479,7 @@ __global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out,
-           RmHandoff ho, const float4* __restrict__ cellinfo)
+           RmHandoff ho, const float4* __restrict__ cellinfo, const uint32_t* __restrict__ occmask)
 {
     const int lane = threadIdx.x;
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
@@ -464,6 +496,17 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     const int sti = tile_order ? tile_order[slot] : slot;                          // super-tile index
     const int ttx = ((sti % sgx) << LX) + (j & ((1 << LX) - 1)), tty = ((sti / sgx) << LY) + (j >> LX);
     if (ttx >= tgx || tty >= tgy) return;
+#if VPFX_RM_OCC_LDS
+    // The cell walk crosses about two empty cells for every occupied one, and learning that a cell is empty used to cost a dependent global
+    // load (31 % of the wave time sat in the walk, scripts/raymarch_phase_profile.py).  The grid's occupancy is one bit per cell: 4 KB at
+    // 32^3, copied into LDS by the wave (one round trip for the whole copy), so that only occupied cells go to memory for their record.
+    __shared__ uint32_t s_occ[VPFX_RM_OCC_WORDS];
+    if (!FLAGS && k.occ_lds) {
+        const int nw = k.Nz * k.Ny;
+        for (int i = lane; i < nw; i += 64) s_occ[i] = occmask[i];
+        __syncthreads();
+    }
+#endif
     // wave = 8 x 8 px.  (16 x 4 px touches fewer brick rows per load -- the L1 tag rate is what binds this kernel -- but loses traversal
     // coherence: 1.50 ms against 1.47; 4 x 16 px: 1.57.)
     // lanes row-major in the tile: the L1 serves a wave-load one lane quad per cycle when the quad's addresses share a 128-B line
@@ -474,7 +517,13 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     const int row = tty * 16 + (wave >> 1) * 8 + ly;
     if (col >= k.W || row >= k.H) return;
 
+#if VPFX_RM_PROBE == 9
+    unsigned long long rm_prof[8] = {};
+    const unsigned long long rm_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long rm_last = rm_t0;
+#endif
     const RayCtx R = ray_setup(k, col, row, scene_depth);
+    VPFX_RM_TICK(0);                                           // ray set-up
 
     // ONE accumulator: a slab kernel (PARTIAL) composites its phase-A slabs, stores that image when the first phase-B slab comes up and
     // starts over (two live images cost 4 registers that the 5-waves/SIMD budget does not have)
@@ -554,11 +603,13 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         // live across the march of a metavoxel.
         auto walk_start = [&](int& cx, int& cy) { cx = (int)floorf(fmaf(ta, R.dgx, R.ogx)); cy = (int)floorf(fmaf(ta, R.dgy, R.ogy)); };
         // returns the current cell (-1: outside the grid) and steps to the next one (branch-free); fin is set with the last cell
+        int ocx = 0, ocy = 0;                                   // the cell walk_step returned (before its step)
         auto walk_step = [&](int& cx, int& cy, bool& fin) -> int {
             // parameter at which the ray leaves cell column cx / cell row cy (from the integer index, never accumulated)
             const float tx = R.dgx != 0.f ? R.ivx * ((float)cx + ((R.dgx > 0.f ? 1.0f : 0.0f) - R.ogx)) : 3.0e38f;
             const float ty = R.dgy != 0.f ? R.ivy * ((float)cy + ((R.dgy > 0.f ? 1.0f : 0.0f) - R.ogy)) : 3.0e38f;
             const int cur = (cx >= 0 && cx < k.Nx && cy >= 0 && cy < k.Ny) ? cy * k.Nx + cx : -1;
+            ocx = cx; ocy = cy;
             fin = !(fminf(tx, ty) < tb);
             const bool stepx = tx < ty;
             cx += stepx ? (R.dgx > 0.f ? 1 : -1) : 0;
@@ -592,6 +643,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
                     // one 16-byte record per cell = (translation of _CameraToMetavoxel, brick slot or -1): occupancy, slot and translation
                     // arrive with ONE load instead of three dependent ones (occupancy -> translation; the rank load runs beside it)
                     if (!FLAGS && cell >= 0) {
+#if VPFX_RM_OCC_LDS
+                        if (k.occ_lds && !((s_occ[zz * k.Ny + ocy] >> ocx) & 1u)) continue;      // empty: no trip to memory
+#endif
                         const float4 q4 = cellinfo[zz * nxy + cell];
                         const int r = rank[cell];
                         if (__float_as_int(q4.w) >= 0) {
@@ -637,7 +691,8 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             F4 src;
             const int ns0 = nsamp;
             const uint2* brick = bricks + (size_t)bi * NV * NV * NV;
-            if (!march_mv<NV, WRAP, FLAGS, GREY>(k, R, brick, trv, src, nsamp)) continue;
+            VPFX_RM_TICK(1);                                   // cell walk: the next occupied metavoxel along the ray
+            if (!march_mv<NV, WRAP, FLAGS, GREY>(k, R, brick, trv, src, nsamp VPFX_RM_PROF_PASS)) { VPFX_RM_TICK(2); continue; }
             if (nsamp != ns0) brick_hit[bi] = 1;
             if (FLAGS && (k.flags & VP_RM_SHOW_BLEND_FUNC)) // debug view: yellow = OVER, cyan = UNDER   RM.shader:174-181
                 src = phaseA ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
@@ -653,7 +708,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
             if (FLAGS && (k.flags & VP_RM_QUANTIZE_UNORM8)) {   // particlesRT is ARGB32: the ROP stores UNORM8 (Q19)    VPR.cs:228
                 d.x = unorm8(d.x); d.y = unorm8(d.y); d.z = unorm8(d.z); d.w = unorm8(d.w);
             }
+            VPFX_RM_TICK(4);                                   // inter-metavoxel blend
         }
+        VPFX_RM_TICK(1);                                       // (the walk that found no further cell in this slab)
         // saturated: everything farther along the ray is multiplied by (1 - dst.a) == 0.  (A saturated phase-A image of a slab
         // also hides the slab's own phase-B image, which is composited behind it.)
         dst = d;
@@ -680,6 +737,12 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
         if (ho.t_out1) ho.t_out1[pi] = encode(storedA ? t0 * (1.0f - dst.w) : t0);
     }
     if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
+#if VPFX_RM_PROBE == 9
+    VPFX_RM_TICK(5);                                           // image / hand-off stores
+    rm_prof[7] = __builtin_amdgcn_s_memtime() - rm_t0;
+    if (lane == (int)__builtin_amdgcn_readfirstlane(__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))))
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_rm_prof[blockIdx.x & 63][i], rm_prof[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -980,7 +1043,8 @@ k_raymarch_flat(RmConsts k, const int* __restrict__ brick_index, const uint2* __
                 const int bi = occ[best_cell];
                 F4 src;
                 const int nsb = nsamp;
-                if (!march_mv<NV, false, false, GREY>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp)) continue;
+                VPFX_RM_PROF_DUMMY
+                if (!march_mv<NV, false, false, GREY>(k, R, bricks + (size_t)bi * NV * NV * NV, mvtrans[bi], src, nsamp VPFX_RM_PROF_PASS)) continue;
                 if (nsamp != nsb) brick_hit[bi] = 1;
                 const float ia = 1.0f - dst.w;
                 dst.x = src.x * ia + dst.x; dst.y = src.y * ia + dst.y; dst.z = src.z * ia + dst.z; dst.w = src.w * ia + dst.w;
@@ -1042,7 +1106,8 @@ k_raymarch_one(RmConsts k, const uint2* __restrict__ brick, float4 tr, const flo
     const RayCtx R = ray_setup(k, col, row, scene_depth);
     F4 src;
     int nsamp = 0;
-    if (!march_mv<NV, WRAP, true, GREY>(k, R, brick, tr, src, nsamp)) return;  // no fragment: the ROP is not touched
+    VPFX_RM_PROF_DUMMY
+    if (!march_mv<NV, WRAP, true, GREY>(k, R, brick, tr, src, nsamp VPFX_RM_PROF_PASS)) return;  // no fragment: the ROP is not touched
     if (k.flags & VP_RM_SHOW_BLEND_FUNC) src = blend_over ? F4{0.5f, 0.5f, 0.f, 1.f} : F4{0.f, 0.5f, 0.5f, 1.f};
     if (k.flags & VP_RM_SHOW_DRAW_ORDER) src = draw_order_color(order_index, k.num_covered);
     const size_t pi = (size_t)row * k.W + col;
@@ -1107,7 +1172,7 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
     const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
     hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS, GREY>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
                        c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out, ho,
-                       (const float4*)c->d_cellinfo);
+                       (const float4*)c->d_cellinfo, (const uint32_t*)c->d_occmask);
 }
 
 template <int NV, bool PARTIAL, bool GREY>
@@ -1159,8 +1224,10 @@ void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, i
 
 }  // namespace
 
-int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, const RmHandoff* handoff)
+int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_under, const RmHandoff* handoff)
 {
+    RmConsts k = k_in;
+    k.occ_lds = (VPFX_RM_OCC_LDS && VPFX_RM_CELLINFO && k.Nx <= 32 && k.Nz * k.Ny <= VPFX_RM_OCC_WORDS) ? 1 : 0;
     const RmHandoff ho = (handoff && d_under) ? *handoff : RmHandoff{};          // slab (partial-image) kernels only
     const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) ? 0 : 1;
     VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
@@ -1182,10 +1249,14 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under,
     // every cell's record starts out "empty" (slot -1), also when nothing is occupied: the walk reads the record of every cell it crosses
     if (!c->d_cellinfo) VP_HIP(hipMalloc((void**)&c->d_cellinfo, c->n3 * sizeof(float4)));
     VP_HIP(hipMemsetAsync(c->d_cellinfo, 0xff, c->n3 * sizeof(float4), c->stream));
+    if (k.occ_lds) {
+        if (!c->d_occmask) VP_HIP(hipMalloc((void**)&c->d_occmask, VPFX_RM_OCC_WORDS * sizeof(uint32_t)));
+        VP_HIP(hipMemsetAsync(c->d_occmask, 0, VPFX_RM_OCC_WORDS * sizeof(uint32_t), c->stream));
+    }
 #endif
     if (nocc > 0) {
         hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans,
-                           c->d_cellinfo);
+                           c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr);
         if (k.flags & VP_RM_SHOW_DRAW_ORDER)
             hipLaunchKernelGGL(k_order_index, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_brick_index, c->d_rank,
                                nocc, c->d_mvtrans);

@@ -58,7 +58,7 @@ struct FillConsts {
 struct RmConsts {
     int W, H, Nx, Ny, Nz, nv, z0, z1;
     int zB, steps, soft, partial;
-    int flags, num_covered, lane_transpose, pad3;  // VP_RM_* bits of vp_raymarch_params.flags; _NumMetavoxelsCovered (VPR.cs:755); lanes run down screen columns
+    int flags, num_covered, lane_transpose, occ_lds;  // (occ_lds: the grid's occupancy bitmask fits k_raymarch's LDS copy, launch_raymarch)  VP_RM_* bits of vp_raymarch_params.flags; _NumMetavoxelsCovered (VPR.cs:755); lanes run down screen columns
     float aspect, neg_inv_tan, zMin, s;
     float mvStep, inv_mvStep, nearc, farc;
     float c2m_lin[9];             // linear part of _CameraToMetavoxel (identical for every MV), rows     VPR.cs:778
@@ -177,6 +177,7 @@ struct vp_ctx {
     // raymarch
     float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
     size_t mvtrans_cap = 0;
+    uint32_t* d_occmask = nullptr; // [Nz][Ny] one bit per cell (Nx <= 32): occupied metavoxels, copied into LDS by k_raymarch for the cell walk
     float4* d_cellinfo = nullptr; // [N^3] (translation, brick slot | -1) per cell: VPFX_RM_CELLINFO A/B variant of the cell walk
     int* d_rank = nullptr;        // [Ny*Nx]
     int* d_tile_order = nullptr;  // [2 x (super-tiles + 8)] dispatch order of k_raymarch (most expensive first), then the float cost estimates
