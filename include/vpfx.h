@@ -255,6 +255,14 @@ int  vp_fill_metavoxel(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz);
 int  vp_raymarch(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, float* rgba_out);
 int  vp_raymarch_device(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params,
                         void* d_rgba_out);
+/* vp_raymarch without the wait ("or offers _async + vp_wait"): the ray-march is queued, a second stream copies the image to
+ * rgba_out as soon as it is complete, and the call returns; the next frame's vp_bin* / vp_fill run beside the copy (33 MB at 1080p).
+ * vp_wait_image blocks until the image has landed in rgba_out (also done by vp_sync).  One image in flight per context: a later
+ * vp_raymarch / vp_raymarch_async waits on the device for the copy before it reuses the context's image.  rgba_out must stay valid until
+ * vp_wait_image and should be page-locked (vp_pin_host_buffer): with a pageable buffer the call blocks for the copy.  On a fan-out
+ * (multi-GPU) context this is the synchronous vp_raymarch and vp_wait_image returns at once. */
+int  vp_raymarch_async(vp_ctx* ctx, const vp_camera* cam, const vp_raymarch_params* params, float* rgba_out);
+int  vp_wait_image(vp_ctx* ctx);
 
 /* The reference's per-metavoxel entry point RenderMetavoxel(xx, yy, zz, orderIndex) (VPR.cs:766-794) on the context's own
  * particlesRT (VPR.cs:228), with the blend state RenderMetavoxels sets around it (VPR.cs:659-662 / 688-691):

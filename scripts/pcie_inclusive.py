@@ -40,4 +40,18 @@ for _ in range(n):
 trp = (time.perf_counter() - t0) / n
 assert np.array_equal(out, img)
 print(f"pinned host buffers: step {dtp*1e3:.3f} ms -> {(st['voxels_filled']+st['samples'])/dtp/1e6:.0f} M(voxels+samples)/s; vp_raymarch (+ D2H) {trp*1e3:.3f} ms")
+# pipelined: vp_raymarch_async + vp_wait_image, the image copy of frame n runs beside bin + fill of frame n + 1 (one frame of latency)
+outs = [out, np.empty_like(out)]
+e.pin(outs[1])
+e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp); e.raymarch_async(cam, rp, outs[0])
+t0 = time.perf_counter()
+for i in range(n):
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world); e.fill(fp)
+    e.wait_image()                                        # frame i's image is in outs[i % 2] from here on
+    e.raymarch_async(cam, rp, outs[(i + 1) % 2])
+e.wait_image()
+dta = (time.perf_counter() - t0) / n
+assert np.array_equal(outs[0], img) and np.array_equal(outs[1], img)
+print(f"pinned + vp_raymarch_async (copy beside the next frame's bin + fill): step {dta*1e3:.3f} ms -> {(st['voxels_filled']+st['samples'])/dta/1e6:.0f} M(voxels+samples)/s")
+e.unpin(outs[1])
 e.unpin(out); e.unpin(sc.particles)

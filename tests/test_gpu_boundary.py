@@ -355,3 +355,33 @@ def test_samples_per_ray_view_and_wave_coherent_traversal(monkeypatch):
             assert g0.stats()["samples"] == g1.stats()["samples"]
         for x in (g0, s0, g1, s1):
             x.close()
+
+
+def test_async_raymarch_overlaps_the_image_copy_with_the_next_frame():
+    """vp_raymarch_async + vp_wait_image ("_async + vp_wait"): the image equals vp_raymarch's bit for bit, the next frame's bin +
+    fill may be queued before the wait, a second async call reuses the context's image only after the first copy, vp_sync also lands it."""
+    sc = S.make_scene("C1", cubemap="r8")
+    e = E.Engine(sc.config())
+    e.set_frame(sc.light_to_world, sc.grid_center)
+    e.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    e.fill(sc.fill_params())
+    cam, rp = sc.camera(), sc.raymarch_params()
+    ref = e.raymarch(cam, rp)
+    a, b = np.zeros_like(ref), np.zeros_like(ref)
+    e.pin(a); e.pin(b)
+    e.raymarch_async(cam, rp, a)
+    e.bin_resident(); e.fill(sc.fill_params())            # the next frame's work, queued while the copy runs
+    e.wait_image()
+    assert np.array_equal(a, ref)
+    sc.set_camera((2.0, 1.0, -1.5))
+    cam2 = sc.camera()
+    ref2 = e.raymarch(cam2, rp)                            # synchronous call between two async ones
+    e.raymarch_async(cam, rp, a)
+    e.raymarch_async(cam2, rp, b)                          # waits on the device for a's copy before it overwrites the context image
+    e.sync()                                               # vp_sync lands the pending image too
+    assert np.array_equal(b, ref2)
+    e.raymarch_async(cam, rp, a); e.wait_image(); e.wait_image()      # a second wait is a no-op
+    assert np.array_equal(a, ref)
+    e.unpin(a); e.unpin(b)
+    e.close()
+

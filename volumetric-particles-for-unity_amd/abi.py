@@ -197,7 +197,7 @@ class vp_unity_frame(C.Structure):
 EXPORTED_SYMBOLS = [
     "vp_create", "vp_destroy", "vp_last_error", "vp_abi_version", "vp_set_stream", "vp_sync", "vp_pin_host_buffer", "vp_unpin_host_buffer",
     "vp_set_frame", "vp_bin", "vp_upload_particles", "vp_bin_resident", "vp_fill", "vp_fill_begin", "vp_fill_metavoxel",
-    "vp_raymarch", "vp_raymarch_device", "vp_clear_particles_rt", "vp_render_metavoxel", "vp_read_particles_rt", "vp_composite_device",
+    "vp_raymarch", "vp_raymarch_device", "vp_raymarch_async", "vp_wait_image", "vp_clear_particles_rt", "vp_render_metavoxel", "vp_read_particles_rt", "vp_composite_device",
     "vp_fill_local", "vp_fill_finish", "vp_fill_finish_gathered", "vp_raymarch_partial_device", "vp_blend_partials_device",
     "vp_blend_partials_range_device",
     "vp_z_boundary", "vp_z_histogram", "vp_set_occluders", "vp_render_light_depth", "vp_render_scene_depth",

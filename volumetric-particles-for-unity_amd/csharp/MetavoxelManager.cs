@@ -106,6 +106,8 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_fill_begin(IntPtr ctx, ref vp_fill_params p);
         [DllImport(LIB)] static extern int vp_fill_metavoxel(IntPtr ctx, int xx, int yy, int zz);
         [DllImport(LIB)] static extern int vp_raymarch(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, IntPtr rgbaOut);
+        [DllImport(LIB)] static extern int vp_raymarch_async(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, IntPtr rgbaOut);   // image lands by vp_wait_image
+        [DllImport(LIB)] static extern int vp_wait_image(IntPtr ctx);
         [DllImport(LIB)] static extern int vp_clear_particles_rt(IntPtr ctx);
         [DllImport(LIB)] static extern int vp_render_metavoxel(IntPtr ctx, ref vp_camera cam, ref vp_raymarch_params p, int xx, int yy, int zz,
                                                                int blendOver, int orderIndex);

@@ -111,6 +111,9 @@ struct vp_ctx {
     bool no_zprofile = false;     // VPFX_NO_ZPROFILE=1 in the environment at vp_create: measurement switch, slab ray-march without the per-slice sample profile
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;                 // vp_raymarch_async: device-to-host copy of the image beside the next frame's kernels
+    hipEvent_t ev_image_ready = nullptr, ev_image_copied = nullptr;
+    bool image_copy_pending = false;
     GridConsts g{};
     bool have_frame = false, have_particles = false, binned = false, filled = false, local_done = false, fill_begun = false;
 

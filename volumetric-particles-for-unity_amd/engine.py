@@ -183,6 +183,16 @@ class Engine:
         self._ck(self.L.vp_raymarch(self.h, C.byref(cam), C.byref(rp), _vp(img)), "vp_raymarch")
         return img
 
+    def raymarch_async(self, cam, rp, out):
+        """vp_raymarch_async: queue the ray-march and the copy of its image into `out` (float32 [H, W, 4], ideally pinned with pin());
+        wait_image() before reading `out`."""
+        if out.shape != (self.H, self.W, 4) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("raymarch_async(out): float32 C-contiguous [H, W, 4] expected")
+        self._ck(self.L.vp_raymarch_async(self.h, C.byref(cam), C.byref(rp), _vp(out)), "vp_raymarch_async")
+
+    def wait_image(self):
+        self._ck(self.L.vp_wait_image(self.h), "vp_wait_image")
+
     def clear_particles_rt(self):
         self._ck(self.L.vp_clear_particles_rt(self.h), "vp_clear_particles_rt")
 
