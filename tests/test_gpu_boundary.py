@@ -385,3 +385,25 @@ def test_async_raymarch_overlaps_the_image_copy_with_the_next_frame():
     e.unpin(a); e.unpin(b)
     e.close()
 
+
+
+def test_manager_async_readback_shows_each_frame_one_frame_late():
+    """asyncReadback (vp_raymarch_async behind the component mirror): frame n returns frame n - 1's image, bit for bit what the synchronous
+    component returned for that frame."""
+    sc = S.make_scene("T0")
+    sync, lazy = _manager(sc), _manager(sc)
+    lazy.asyncReadback = True
+    cams = [sc.camera()]
+    sc.set_camera((2.0, 1.0, -19.0))
+    cams.append(sc.camera())
+    moved = sc.particles.copy()
+    moved["position"] += 0.4
+    frames = [(0, sc.particles, cams[0]), (1, sc.particles, cams[1]), (2, moved, cams[1]), (3, moved, cams[0])]
+    refs = [sync.OnPostRender(f, p, sc.layout, c).copy() for f, p, c in frames]
+    got = []
+    for f, p, c in frames:
+        g = lazy.OnPostRender(f, p, sc.layout, c)                 # (a view of one of the two read-back buffers: valid until the call after next)
+        got.append(None if g is None else g.copy())
+    assert got[0] is None
+    for i in range(1, len(frames)):
+        np.testing.assert_array_equal(got[i], refs[i - 1])

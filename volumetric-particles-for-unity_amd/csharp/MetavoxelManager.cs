@@ -42,6 +42,7 @@ namespace MetavoxelEngine
         public int[] gpuDevices = new int[0];      // HIP ordinals; empty / one entry = one GPU.  N entries: the library cuts the grid into N
                                                    // light-axis slabs, one per GPU, with RCCL inside (vp_config.num_devices / devices[])
         public int rebalanceInterval = 240;        // multi-GPU: frames between vp_rebalance calls (0 = never re-cut the slabs)
+        public bool asyncReadback = false;         // vp_raymarch_async: the image is shown one frame late, its copy runs beside the next frame's fill
         public bool useRenderThread = false;       // run the frame from Unity's render thread (GL.IssuePluginEvent) instead of OnPostRender
 
         // ---- C ABI (include/vpfx.h) ---------------------------------------------------------------------
@@ -321,10 +322,17 @@ namespace MetavoxelEngine
             if (!filledOnce) return;                                       // nothing filled yet: nothing to march
             vp_camera cam; vp_raymarch_params rp;
             CameraAndParams(out cam, out rp);
+            if (asyncReadback) {
+                // last frame's image has had a whole frame to land in `rgba`: show it, then queue this frame's march + copy
+                if (imageInFlight && Check(vp_wait_image(ctx), "vp_wait_image")) { particlesTex.SetPixelData(rgba, 0); particlesTex.Apply(false); }
+                imageInFlight = Check(vp_raymarch_async(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch_async");
+                return;
+            }
             Check(vp_raymarch(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch");
             particlesTex.SetPixelData(rgba, 0);
             particlesTex.Apply(false);
         }
+        bool imageInFlight = false;
 
         // The reference's per-metavoxel entry point (VPR.cs:766-794): one metavoxel marched and blended into the library's
         // particlesRT with the blend state of its phase (blendOver: VPR.cs:659-662, else :688-691).  ClearParticlesRT() first

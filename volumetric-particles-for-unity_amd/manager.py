@@ -46,6 +46,10 @@ class MetavoxelManager:
         self.screenWidth, self.screenHeight, self.device = screenWidth, screenHeight, device
         # ---- added by this binding (same names as csharp/MetavoxelManager.cs): the device list of a multi-GPU fan-out context
         self.gpuDevices, self.multiFlags, self.rebalanceInterval = tuple(gpuDevices), multiFlags, rebalanceInterval
+        self.asyncReadback = False          # vp_raymarch_async: RenderMetavoxels returns LAST frame's image (None on the first frame; a view of one of
+                                            # two read-back buffers, valid until the call after next), the copy of this frame's image runs beside the
+                                            # next frame's bin + fill
+        self._async_bufs, self._async_i, self._async_pending = None, 0, False
         # ---- scene bindings (dirLight, gridCenter, particleSys, displacement texture)
         self.lightToWorld = np.eye(4, dtype=np.float32).T.reshape(16).copy()
         self.wsGridCenter = np.zeros(3, dtype=np.float32)                       # VPR.cs:138
@@ -89,6 +93,8 @@ class MetavoxelManager:
             self.BinParticlesToMetavoxels(particles, layout)                    # :197
             self.FillMetavoxels()                                               # :198
         self.particlesRT = self.RenderMetavoxels(camera)                        # :207
+        if self.particlesRT is None:                                            # asyncReadback, first frame: nothing to show yet
+            return None
         if mainSceneRT is not None:                                             # Blit(particlesRT, mainSceneRT, matBlendParticles) :210
             p = self.particlesRT
             mainSceneRT[..., :3] = p[..., :3] + mainSceneRT[..., :3] * (1.0 - p[..., 3:4])
@@ -172,7 +178,20 @@ class MetavoxelManager:
 
     def RenderMetavoxels(self, camera):
         rp, keep = self._raymarch_params()
-        return self._engine.raymarch(camera, rp)
+        if not self.asyncReadback:
+            return self._engine.raymarch(camera, rp)
+        if self._async_bufs is None:
+            self._async_bufs = [np.zeros((self._engine.H, self._engine.W, 4), dtype=np.float32) for _ in range(2)]
+            for b in self._async_bufs:
+                self._engine.pin(b)
+        last = None
+        if self._async_pending:
+            self._engine.wait_image()                                           # last frame's image has landed
+            last = self._async_bufs[self._async_i]
+        self._async_i ^= 1
+        self._engine.raymarch_async(camera, rp, self._async_bufs[self._async_i])
+        self._async_pending = True
+        return last
 
     def RenderMetavoxel(self, camera, xx, yy, zz, orderIndex=0, blendOver=False):
         """VPR.cs:766-794: one metavoxel marched and blended into particlesRT with the blend state of its phase."""
