@@ -210,8 +210,9 @@ int  vp_sync(vp_ctx* ctx);
 /* Optional: page-lock a caller-owned host buffer that is handed to vp_bin / vp_upload_particles (the Particle[] array) or
  * vp_raymarch (the RGBA read-back) every frame, so that the PCIe copies run at DMA speed instead of through a bounce
  * buffer (33 MB read-back at 1080p: 1.45 -> ~0.6 ms).  The caller keeps the buffer alive and unmoved until
- * vp_unpin_host_buffer (a pinned managed array in C#: GCHandle.Alloc(..., Pinned)).  Purely a speed hint: every entry
- * point accepts unpinned memory. */
+ * vp_unpin_host_buffer (a pinned managed array in C#: GCHandle.Alloc(..., Pinned)) -- and must unpin it BEFORE freeing it: the page lock
+ * belongs to the address range, and memory the allocator hands out again inside a stale range makes later copies fail (vp_destroy does not
+ * know the caller's buffers).  Purely a speed hint: every entry point accepts unpinned memory. */
 int  vp_pin_host_buffer(vp_ctx* ctx, void* ptr, uint64_t bytes);
 int  vp_unpin_host_buffer(vp_ctx* ctx, void* ptr);
 

@@ -407,3 +407,4 @@ def test_manager_async_readback_shows_each_frame_one_frame_late():
     assert got[0] is None
     for i in range(1, len(frames)):
         np.testing.assert_array_equal(got[i], refs[i - 1])
+    lazy.OnDestroy(); sync.OnDestroy()                     # (unpins the read-back buffers before numpy frees them)

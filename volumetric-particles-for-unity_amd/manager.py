@@ -81,6 +81,23 @@ class MetavoxelManager:
         self._engine = Engine(cfg)
         self._frame_dirty = True
 
+    def OnDestroy(self):
+        """Release the read-back buffers' page locks and the native context (the C# shim's OnDestroy)."""
+        eng = self._engine
+        if eng is not None and getattr(eng, "h", None):
+            if self._async_bufs is not None:
+                eng.sync()                                  # lands a pending image before its buffer loses the page lock
+                for b in self._async_bufs:
+                    eng.unpin(b)
+            eng.close()
+        self._async_bufs, self._async_pending, self._engine = None, False, None
+
+    def __del__(self):
+        try:
+            self.OnDestroy()
+        except Exception:
+            pass
+
     def OnPostRender(self, frameCount, particles, layout, camera, mainSceneRT=None):
         """VPR.cs:181-220.  Returns particlesRT (and composites it over mainSceneRT in place when given)."""
         # the reference's first OnPostRender has frameCount % updateInterval == 0 (frame 0); a host that starts on another frame
