@@ -176,7 +176,7 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
     k->nearc = cam->near_clip;
     k->farc = cam->far_clip > 0.f ? cam->far_clip : 3.0e38f;
     // _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld (VPR.cs:774-778).  Its linear part is
-    // the same for every MV; the per-MV translation column is finished on the device (k_mv_trans).
+    // the same for every MV; the per-MV translation column is finished on the device (k_rm_prepare).
     {
         const float inv = 1.0f / g.s;
         for (int r = 0; r < 3; ++r)

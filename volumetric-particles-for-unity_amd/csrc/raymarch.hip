@@ -77,7 +77,7 @@ extern "C" __attribute__((visibility("default"))) int vpfx_rm_probe_read(unsigne
 #endif
 #define VPFX_RM_OCC_WORDS 1024  // Nz * Ny <= 1024 and Nx <= 32 (C1 .. C4); larger grids walk on the per-cell records alone
 #ifndef VPFX_RM_CELLINFO
-#define VPFX_RM_CELLINFO 1      // per-cell (translation, brick slot) records for the streaming cell walk (see k_raymarch): 0.967 -> 0.951 ms at C3; 0 = A/B
+#define VPFX_RM_CELLINFO 1      // per-cell (translation, brick slot) records for the streaming cell walk (see k_raymarch; written by k_rm_prepare): 0.967 -> 0.951 ms at C3; 0 = A/B
 #endif
 
 // Explicitly issued 16-byte loads for the two-samples-per-iteration loop: the compiler otherwise sinks the second
@@ -355,27 +355,40 @@ __device__ __forceinline__ F4 draw_order_color(int order_index, int num_covered)
     return sel == 0 ? F4{0.f, v, 0.f, 1.f} : sel == 1 ? F4{0.f, 0.f, v, 1.f} : F4{v, 0.f, 0.f, 1.f};
 }
 
-// Translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld for every occupied MV
-// (VPR.cs:774-778), same operation order as the matrix product the reference does per draw.
+// Everything the march needs per frame in ONE launch over all N^3 cells (it was four memsets and a kernel over the occupied metavoxels):
+// the translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld of every occupied metavoxel (VPR.cs:774-778,
+// same operation order as the matrix product the reference does per draw) into mvtrans[slot] and into the cell's record, "empty" records for the other cells, the
+// occupancy bitmask rows (the thread of a row's first cell builds the word), brick_hit[slot] = 0, the sample counter = 0.
 __global__ void __launch_bounds__(256)
-k_mv_trans(RmConsts k, const int* __restrict__ occ_list, const float* __restrict__ mvPos, int n, float4* __restrict__ out,
-           float4* __restrict__ cellinfo /* nullable: [N^3] records (translation, brick slot), preset to -1 */,
-           uint32_t* __restrict__ occmask /* nullable: [Nz][Ny] occupancy bits, preset to 0 */)
+k_rm_prepare(RmConsts k, const int* __restrict__ brick_index, const float* __restrict__ mvPos, int n3, float4* __restrict__ mvtrans,
+             float4* __restrict__ cellinfo /* nullable */, uint32_t* __restrict__ occmask /* nullable */, int* __restrict__ brick_hit,
+             unsigned long long* __restrict__ samples)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int mi = occ_list[i];
-    const float mx = mvPos[3 * mi], my = mvPos[3 * mi + 1], mz = mvPos[3 * mi + 2];
-    float tr[3];
+    const int mi = blockIdx.x * 256 + threadIdx.x;
+    if (mi == 0) *samples = 0ull;
+    if (mi >= n3) return;
+    const int slot = brick_index[mi];
+    if (slot >= 0) {
+        const float mx = mvPos[3 * mi], my = mvPos[3 * mi + 1], mz = mvPos[3 * mi + 2];
+        float tr[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float a = k.inv_rows[r * 3], b = k.inv_rows[r * 3 + 1], c = k.inv_rows[r * 3 + 2];
-        const float t = -((a * mx + b * my) + c * mz);
-        tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + c * k.c2w_t[2]) + t * k.c2w_t[3];
+        for (int r = 0; r < 3; ++r) {
+            const float a = k.inv_rows[r * 3], b = k.inv_rows[r * 3 + 1], c = k.inv_rows[r * 3 + 2];
+            const float t = -((a * mx + b * my) + c * mz);
+            tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + c * k.c2w_t[2]) + t * k.c2w_t[3];
+        }
+        mvtrans[slot] = make_float4(tr[0], tr[1], tr[2], 0.f);
+        if (cellinfo) cellinfo[mi] = make_float4(tr[0], tr[1], tr[2], __int_as_float(slot));
+        brick_hit[slot] = 0;
+    } else if (cellinfo) {
+        const float e = __int_as_float(-1);
+        cellinfo[mi] = make_float4(e, e, e, e);                          // the walk reads the record of every cell it crosses
     }
-    out[i] = make_float4(tr[0], tr[1], tr[2], 0.f);
-    if (cellinfo) cellinfo[mi] = make_float4(tr[0], tr[1], tr[2], __int_as_float(i));
-    if (occmask) atomicOr(&occmask[mi / k.Nx], 1u << (mi % k.Nx));             // mi = (zz Ny + yy) Nx + xx
+    if (occmask && mi % k.Nx == 0) {
+        uint32_t word = 0;
+        for (int x = 0; x < k.Nx; ++x) word |= (brick_index[mi + x] >= 0 ? 1u : 0u) << x;
+        occmask[mi / k.Nx] = word;                                       // row (zz, yy)
+    }
 }
 
 // Dispatch order of the screen super-tiles (64x32 px): most expensive first, so that the long rays are not what the
@@ -1230,7 +1243,6 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
     k.occ_lds = (VPFX_RM_OCC_LDS && VPFX_RM_CELLINFO && k.Nx <= 32 && k.Nz * k.Ny <= VPFX_RM_OCC_WORDS) ? 1 : 0;
     const RmHandoff ho = (handoff && d_under) ? *handoff : RmHandoff{};          // slab (partial-image) kernels only
     const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) ? 0 : 1;
-    VP_HIP(hipMemsetAsync(c->d_samples, 0, sizeof(unsigned long long), c->stream));
     const int nocc = c->h_meta.occupied;
     if ((size_t)nocc > c->mvtrans_cap) {
         if (c->d_mvtrans) VP_HIP(hipFree(c->d_mvtrans));
@@ -1244,19 +1256,14 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
         VP_HIP(hipMalloc((void**)&c->d_brick_hit, ((size_t)nocc + nocc / 8 + 16) * sizeof(int)));
         c->brick_hit_cap = (size_t)nocc + nocc / 8 + 16;
     }
-    VP_HIP(hipMemsetAsync(c->d_brick_hit, 0, c->brick_hit_cap * sizeof(int), c->stream));
 #if VPFX_RM_CELLINFO
-    // every cell's record starts out "empty" (slot -1), also when nothing is occupied: the walk reads the record of every cell it crosses
     if (!c->d_cellinfo) VP_HIP(hipMalloc((void**)&c->d_cellinfo, c->n3 * sizeof(float4)));
-    VP_HIP(hipMemsetAsync(c->d_cellinfo, 0xff, c->n3 * sizeof(float4), c->stream));
-    if (k.occ_lds) {
-        if (!c->d_occmask) VP_HIP(hipMalloc((void**)&c->d_occmask, VPFX_RM_OCC_WORDS * sizeof(uint32_t)));
-        VP_HIP(hipMemsetAsync(c->d_occmask, 0, VPFX_RM_OCC_WORDS * sizeof(uint32_t), c->stream));
-    }
+    if (k.occ_lds && !c->d_occmask) VP_HIP(hipMalloc((void**)&c->d_occmask, VPFX_RM_OCC_WORDS * sizeof(uint32_t)));
 #endif
+    // one launch prepares the frame: translations, per-cell records, occupancy rows, cleared hit flags and sample counter (k_rm_prepare)
+    hipLaunchKernelGGL(k_rm_prepare, dim3((unsigned)((c->n3 + 255) / 256)), dim3(256), 0, c->stream, k, c->d_brick_index, c->d_mvPos, (int)c->n3,
+                       c->d_mvtrans, c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr, c->d_brick_hit, c->d_samples);
     if (nocc > 0) {
-        hipLaunchKernelGGL(k_mv_trans, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_mvPos, nocc, c->d_mvtrans,
-                           c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr);
         if (k.flags & VP_RM_SHOW_DRAW_ORDER)
             hipLaunchKernelGGL(k_order_index, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_brick_index, c->d_rank,
                                nocc, c->d_mvtrans);
@@ -1276,7 +1283,7 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
 
 int launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_over, int order_index, float* d_img)
 {
-    // translation column of this metavoxel's _CameraToMetavoxel, same operation order as k_mv_trans (VPR.cs:774-778)
+    // translation column of this metavoxel's _CameraToMetavoxel, same operation order as k_rm_prepare (VPR.cs:774-778)
     const float* mp = c->h_mvPos + 3 * (size_t)mi;
     float tr[3];
     for (int r = 0; r < 3; ++r) {
