@@ -306,14 +306,19 @@ k_sort_lists(const int* __restrict__ occ_list, const int* __restrict__ offsets, 
 __global__ void __launch_bounds__(256)
 k_col_ordinal(const int* __restrict__ brick_index, int nxy, int z0, int z1, int* __restrict__ ord, int* __restrict__ colcount)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // one wave per column, one lane per slice (64 at a time): the ordinal is the number of occupied slices below the lane in the ballot.
+    // (One thread per column walked its slices one dependent load after the other: 11 us at C3 for 1 024 threads.)
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nxy) return;
     int n = 0;
-    for (int zz = z0; zz < z1; ++zz) {
-        const int mi = zz * nxy + i;
-        if (brick_index[mi] >= 0) ord[mi] = n++;
+    for (int zb = z0; zb < z1; zb += 64) {
+        const int zz = zb + lane;
+        const bool occ = zz < z1 && brick_index[zz * nxy + i] >= 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
+        if (occ) ord[zz * nxy + i] = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        n += __builtin_popcountll(m);
     }
-    colcount[i] = n;
+    if (lane == 0) colcount[i] = n;
 }
 
 }  // namespace
@@ -356,7 +361,7 @@ int launch_bin(vp_ctx* c)
     if (prefixed) hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(SCAN_TILE), 0, c->stream, (TileTotals*)c->d_scan_totals, ntiles);
     hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
                        (const TileTotals*)c->d_scan_totals, ntiles, prefixed, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
-    hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 255) / 256), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
+    hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 3) / 4), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
     VP_HIP(hipGetLastError());
     // totals are needed on the host to size the pair and brick pools
     VP_HIP(hipMemcpyAsync(&c->h_meta, c->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, c->stream));
