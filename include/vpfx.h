@@ -166,6 +166,11 @@ typedef struct vp_raymarch_params {
                                      (n, n, n, 1) f32 -- the samples-per-ray heat map of SURVEY 8(f) row 4.  Unlike the reference's debug
                                      views it leaves the saturation early-out on: it shows the work the frame really did */
 
+#define VP_RM_NO_EARLY_OUT     32  /* this call marches every lattice sample of SURVEY 8(d)'s formula (sum over pixels and metavoxels of
+                                     max(0, tExit - tEntry + 1)) -- the saturation early-out off for ONE call, on the resident bricks (the
+                                     per-context form is vp_config.no_early_out).  Same image up to rounding; vp_stats.samples then is the
+                                     formula count.  Does not select the debug-view kernels */
+
 /* An opaque occluder: oriented box (the demo scene's ground/back planes and cubes are boxes).  Used to PRODUCE the two
  * scene-occlusion inputs of the path on the GPU instead of reading them back from Unity render targets:
  *   light depth map  <- lightCamera.RenderWithShader(GenerateLightDepthMap)   VPR.cs:184, 320-367, LDM.shader:6 (Cull Front:

@@ -26,6 +26,7 @@ VP_RM_SHOW_NUM_SAMPLES = 2
 VP_RM_SHOW_BLEND_FUNC = 4
 VP_RM_SHOW_DRAW_ORDER = 8
 VP_RM_SHOW_RAY_SAMPLES = 16
+VP_RM_NO_EARLY_OUT = 32
 
 VP_BRICKS_RGBA16F, VP_BRICKS_GREY_ZPAIR = 0, 1
 VP_CUBEMAP_F32 = 0

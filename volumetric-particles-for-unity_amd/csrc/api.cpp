@@ -116,9 +116,9 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
         if (e == hipSuccess) e = hipMemcpyAsync(d_cube, p->cubemap, bytes, hipMemcpyHostToDevice, c->stream);
         int rc = VP_OK;
         if (e == hipSuccess) rc = launch_build_cubequads(c, d_cube, p->cubemap_format, S, d_bad);
-        // R8 maps that fit LDS (6 (S+2)^2 bytes <= 160 KB, i.e. S <= 163) also get the padded byte table of the persistent LDS fill
+        // R8 maps that fit LDS (6 (S+2)^2 bytes <= 160 KB, i.e. S <= 162) also get the padded byte table of the persistent LDS fill
         c->cube_u8_S = 0;
-        if (e == hipSuccess && !rc && p->cubemap_format == VP_CUBEMAP_R8 && cube_u8_bytes(S) <= (size_t)160 * 1024) {
+        if (e == hipSuccess && !rc && p->cubemap_format == VP_CUBEMAP_R8 && cube_u8_bytes(S) <= (size_t)160 * 1024 - 1024 /* minus k_fill_lds static LDS */) {
             const size_t need = cube_u8_bytes(S);
             if (need > c->cube_u8_cap) {
                 if (c->d_cube_u8) (void)hipFree(c->d_cube_u8);

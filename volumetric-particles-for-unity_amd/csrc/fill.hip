@@ -60,6 +60,14 @@ extern "C" __attribute__((visibility("default"))) int vpfx_probe_read(unsigned l
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
 #endif
+// units per global-counter atomic of the persistent LDS kernel (workgroup-level claim, see k_fill_lds); 1 = one device-scope atomic per unit (A/B)
+#ifndef VPFX_FILL_CLAIM
+#define VPFX_FILL_CLAIM 16
+#endif
+#ifndef VPFX_FILL_CLAIM_PREF
+#define VPFX_FILL_CLAIM_PREF 15      // the slot whose wave fetches the next block (measured at C3: slot 0 / 12 / 15 -> 2.99 / 2.965 / 2.95 ms)
+#endif
+#define VPFX_FILL_CLAIM_RING 64      // blocks remembered per workgroup (power of two)
 #ifndef VPFX_FILL_PIPE
 #define VPFX_FILL_PIPE 4      // 2..6; measured at C3: 2 -> 5.33 ms, 3 -> 5.07 (4 waves/SIMD), 4 -> 4.80 (3 waves/SIMD)
 #endif
@@ -718,6 +726,14 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
            int nitems, FillChain ch)
 {
     extern __shared__ uint32_t lds_cube[];
+#if VPFX_FILL_CLAIM > 1
+    __shared__ unsigned s_ticket;
+    __shared__ unsigned long long s_block[VPFX_FILL_CLAIM_RING];           // (block + 1) << 32 | first unit of the block; 0 = not fetched yet
+    if (threadIdx.x < VPFX_FILL_CLAIM_RING) s_block[threadIdx.x] = 0ull;
+    if (threadIdx.x == 64) s_ticket = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) s_block[0] = (1ull << 32) | (unsigned)atomicAdd(p_counter, VPFX_FILL_CLAIM);     // block 0 (in flight during the table copy)
+#endif
     for (int i = threadIdx.x; i < table_dwords; i += 64 * VPFX_FILL_LDS_WAVES) lds_cube[i] = p_cube_u8[i];
     __syncthreads();
     const unsigned lds_base = (unsigned)(size_t)lds_cube;       // low half of the flat address of an LDS object = its LDS byte offset
@@ -729,10 +745,44 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
     unsigned long long prof_last = prof_t0;
 #endif
     for (;;) {
+#if VPFX_FILL_CLAIM > 1
+        // Workgroup-level claim (round 4).  One device-scope atomicAdd per UNIT on one address hands units out at 11.7 ns apiece (181 k units:
+        // a 2.12 ms floor under the kernel, profiles/r03_fill_whatif_C3_r8.txt p5 == p7).  Here the 16 waves of the workgroup draw TICKETS
+        // from an LDS counter; ticket t is slot t % CLAIM of the workgroup's block t / CLAIM, a block being CLAIM consecutive units taken
+        // from the global counter with ONE atomicAdd.  The wave that draws slot PREF of block b fetches block b + 1 -- after it has seen
+        // block b's base, so a workgroup's blocks ascend -- and publishes (b + 2) << 32 | base in a ring; a wave whose block is not there
+        // yet polls LDS (a memory round trip at most).  Unlike a per-wave batch the CLAIM units of a block start as waves come free, one
+        // ticket apart, and a fetched block waits (CLAIM - PREF) tickets at most, so the z-major hand-out the chain relies on is kept:
+        // the lowest unfinished unit is either running or in a block whose workgroup's waves all run LOWER units (tickets and blocks both
+        // ascend), which finish without waiting for anything unfinished and then draw it.
+        constexpr unsigned CL = VPFX_FILL_CLAIM, PREF = VPFX_FILL_CLAIM_PREF < CL ? VPFX_FILL_CLAIM_PREF : CL - 1;
+        unsigned tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        const unsigned blk = tk / CL, slot = tk % CL;
+        unsigned long long bw = __hip_atomic_load(&s_block[blk & (VPFX_FILL_CLAIM_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (unsigned spins = 0; (unsigned)(bw >> 32) != blk + 1u; ++spins) {
+            // a tag beyond the awaited one would mean the ring lapped a wave that sat RING x CLAIM tickets between two instructions: report, never mis-assign
+            if ((unsigned)(bw >> 32) > blk + 1u || spins > ch.spin_limit) { *ch.error = 1; bw = ((unsigned long long)(blk + 1u) << 32) | 0x7fffffffull; break; }
+            __builtin_amdgcn_s_sleep(1);
+            bw = __hip_atomic_load(&s_block[blk & (VPFX_FILL_CLAIM_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (slot == PREF) {
+            int nb = 0;
+            if (lane == 0) {
+                nb = atomicAdd(p_counter, (int)CL);
+                __hip_atomic_store(&s_block[(blk + 1u) & (VPFX_FILL_CLAIM_RING - 1)], ((unsigned long long)(blk + 2u) << 32) | (unsigned)nb,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        const int item = (int)((unsigned)bw & 0x7fffffffu) + (int)slot;
+        if (item >= nitems) break;
+#else
         int item = 0;
         if (lane == 0) item = atomicAdd(p_counter, 1);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= nitems) break;
+#endif
         const int sub = item % TPC;
         const int px = (sub % T8) * 8 + (lane & 7), py = (sub / T8) * 8 + (lane >> 3);
         // unit = (occupied metavoxel, tile), metavoxels z-major (a unit's producer is always claimed before it)
@@ -915,7 +965,7 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     auto kernel = k_fill_lds<NV, MODE, TAB, DONE>;
     // dynamic LDS above 64 KB is an opt-in per kernel AND per device: asked for before every launch (a cached "granted" flag would be
     // per process, and a host driving several GPUs launches the same instantiation on each of them)
-    { int rc = allow_big_lds(c, kernel, 160 * 1024); if (rc) return rc; }
+    { int rc = allow_big_lds(c, kernel, 160 * 1024 - 1024 /* the kernel's static LDS: ticket counter + block ring */); if (rc) return rc; }
     constexpr int TPC = (NV / 8) * (NV / 8);
     FillChain ch{};
     const int nitems = c->h_meta.occupied * TPC;

@@ -1242,7 +1242,8 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
     RmConsts k = k_in;
     k.occ_lds = (VPFX_RM_OCC_LDS && VPFX_RM_CELLINFO && k.Nx <= 32 && k.Nz * k.Ny <= VPFX_RM_OCC_WORDS) ? 1 : 0;
     const RmHandoff ho = (handoff && d_under) ? *handoff : RmHandoff{};          // slab (partial-image) kernels only
-    const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) ? 0 : 1;
+    const int early_out = (c->cfg.no_early_out == 1 || (k.flags & (VP_RM_NO_EARLY_OUT | VP_RM_SHOW_NUM_SAMPLES | VP_RM_SHOW_BLEND_FUNC | VP_RM_SHOW_DRAW_ORDER))) ? 0 : 1;
+    k.flags &= ~VP_RM_NO_EARLY_OUT;                     // a launch switch, not a path of the FLAGS kernels
     const int nocc = c->h_meta.occupied;
     if ((size_t)nocc > c->mvtrans_cap) {
         if (c->d_mvtrans) VP_HIP(hipFree(c->d_mvtrans));
