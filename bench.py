@@ -77,7 +77,7 @@ def cpu_quota_cores():
         return None
 
 
-def cpu_baseline(sc, threads=0):
+def cpu_baseline(sc, threads=0, boxes=None):
     """Time the CPU oracle (a port of the reference's algorithm; the reference itself is C# + HLSL and cannot run
     here) on the GPU box's host cores, compiled -march=native on that box.  Reported, not shipped: this is the only place bench.py
     touches oracle/."""
@@ -88,6 +88,8 @@ def cpu_baseline(sc, threads=0):
         # take turns being throttled -- the honest core count of this leg is the quota
         threads = max(1, int(quota + 0.5))
     o = O.Oracle(sc.config(), threads=threads, native=True)
+    if boxes is not None:
+        o.set_occluders(boxes)
     o.set_frame(sc.light_to_world, sc.grid_center)
     t0 = time.perf_counter()
     o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
@@ -112,6 +114,8 @@ def cpu_baseline(sc, threads=0):
     # to the whole step with the per-unit rates (a full single-thread step would take minutes)
     zmid = sc.N[2] // 2
     o1 = O.Oracle(sc.config(slab=(zmid, zmid + 1)), threads=1, native=True)
+    if boxes is not None:
+        o1.set_occluders(boxes)
     o1.set_frame(sc.light_to_world, sc.grid_center)
     o1.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     s0 = time.perf_counter()
@@ -180,7 +184,15 @@ def main():
     if multi_process:
         dist.init_process_group("gloo")          # control plane only: unique id, barrier, timing reduction.  RCCL belongs to the library.
 
-    sc = S.make_scene(args.config, cubemap=args.cubemap)
+    demo_boxes = None
+    if args.config == "DEMO":
+        # the reference's own scene (Assets/Volumetric_Particle_System.unity:9013-9026, 6118): 10^3 metavoxels x 32^3 voxels, the demo
+        # emitter's <= 60 particles, 1024 x 768, ground / wall / cubes as occluders, bin + fill every 2nd frame (updateInterval 2, VPR.cs:186)
+        sc, _, demo_boxes = S.make_demo_scene()
+        if args.cubemap == "r8":
+            sc.cubemap = S.make_cubemap_r8()
+    else:
+        sc = S.make_scene(args.config, cubemap=args.cubemap)
     if args.displacement_scale is not None:
         sc.displacement_scale = float(args.displacement_scale)
 
@@ -238,6 +250,8 @@ def main():
             torch.cuda.empty_cache()
 
     eng = E.Engine(cfg)
+    if demo_boxes is not None:
+        eng.set_occluders(demo_boxes)
     eng.set_frame(sc.light_to_world, sc.grid_center)
     eng.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)      # inputs resident in HBM from here on
     fp_first, fp = sc.fill_params(), sc.fill_params()
@@ -245,10 +259,15 @@ def main():
     cam, rp = sc.camera(), sc.raymarch_params()
     image = torch.empty((sc.height, sc.width, 4), device=device)                # particlesRT on the display GPU (rank 0)
 
+    update_interval = 2 if args.config == "DEMO" else 1
+    frame_no = [0]
+
     def step(first=False):
-        eng.bin_resident()
-        eng.fill(fp_first if first else fp)
+        if first or frame_no[0] % update_interval == 0:                         # Time.frameCount % updateInterval == 0   VPR.cs:186
+            eng.bin_resident()
+            eng.fill(fp_first if first else fp)
         eng.raymarch_device(cam, rp, image.data_ptr())
+        frame_no[0] += 1
 
     sync_devices = list(range(N)) if (N > 1 and not multi_process and not args.share_gpu) else [local_rank]
 
@@ -260,6 +279,14 @@ def main():
             torch.cuda.synchronize(d)
 
     step(first=True)
+    # SURVEY 8(d) defines Msamples/s on the FORMULA count (sum over pixels and metavoxels of max(0, tExit - tEntry + 1)): one untimed ray-march
+    # with the saturation early-out off (VP_RM_NO_EARLY_OUT) executes exactly those samples on the resident bricks.  The timed frames keep the
+    # early-out (same image), so both counts and both rates are reported.
+    rp_all = sc.raymarch_params()
+    rp_all.flags |= abi.VP_RM_NO_EARLY_OUT
+    eng.raymarch_device(cam, rp_all, image.data_ptr())
+    eng.sync()
+    samples_formula_local = eng.stats()["samples"]
     # N > 1: re-cut the slabs twice from the measured work (pairs per slice, samples executed per slice, kernel times), then keep the cut:
     # vp_rebalance makes the NEXT ray-march record its per-slice samples and the bin after that re-cut, hence the extra step at the end
     for i in range(max(args.warmup - 1, 3 if N > 1 else 0)):
@@ -268,6 +295,7 @@ def main():
         step()
     barrier()
     k_fill, k_rm, k_bin, k_fin = [], [], [], []
+    frame_no[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -280,7 +308,7 @@ def main():
     st = eng.stats()
     info = eng.multi_info()
     t = torch.tensor([dt], dtype=torch.float64)
-    counts = torch.tensor([st["voxels_filled"], st["samples"], st["occupied_mv"], st["pairs"], st["bricks_sampled"]], dtype=torch.float64)
+    counts = torch.tensor([st["voxels_filled"], st["samples"], st["occupied_mv"], st["pairs"], st["bricks_sampled"], samples_formula_local], dtype=torch.float64)
     stage_max = torch.tensor([float(np.mean(k_bin)), float(np.mean(k_fill)), float(np.mean(k_rm)), float(np.mean(k_fin)) if k_fin else 0.0],
                              dtype=torch.float64)
     per_rank = torch.zeros((max(N, 1), 5), dtype=torch.float64)                 # samples + the four stage kernel times of every rank
@@ -294,7 +322,7 @@ def main():
         dist.all_reduce(stage_max, op=dist.ReduceOp.MAX)          # slowest rank per stage (kernel time, HIP events)
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
     dt = float(t.item())
-    voxels, samples, occupied, pairs, bricks_sampled = [float(x) for x in counts.tolist()]
+    voxels, samples, occupied, pairs, bricks_sampled, samples_formula = [float(x) for x in counts.tolist()]
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -337,6 +365,9 @@ def main():
             r["frac"] = r["achieved"] / r["peak"]
             tr = traffic.get(r["kernel"])
             r["traffic"] = tr["traffic_bytes"] if tr else None
+            # bench.py cannot collect PMC counters: everything below (traffic, limiter, valu_issue) is read from profiles/*.json, measured with
+            # rocprofv3 on these kernel sources (fingerprint-checked) in an EARLIER run of this same command -- not in this run
+            r["measured_in_this_run"] = {"achieved": True, "avg_ms": True, "traffic": False, "limiter": False, "valu_issue": False}
             if tr:
                 r["traffic_source"] = (f"profiles/traffic_{args.config}_{args.cubemap}.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes of "
                                        f"this command on these kernel sources, sha {sha})")
@@ -346,6 +377,8 @@ def main():
             r["limiter"] = limiters.get(r["kernel"])
             if lnote and not r["limiter"]:
                 r["limiter_note"] = lnote
+            # second roofline: VALU issue (what actually bounds these kernels) -- class counters x per-class issue cycles, <= 1
+            r["valu_issue"] = (r["limiter"] or {}).get("valu_issue")
         dom = "fill" if fill_t * 1e3 >= smax[2] else "raymarch"
         executed = (voxels, samples)
         if ref_units is not None:
@@ -355,13 +388,14 @@ def main():
         ex = info["exchange_ms"]
         out = {
             "metric": baseline_metric(),
-            "value": (voxels + samples) / (dt / args.steps) / 1e6,
+            "value": (voxels / update_interval + samples) / (dt / args.steps) / 1e6,        # (DEMO: the fill runs every 2nd frame)
             "unit": "M(voxels+samples)/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 compute / f16 voxel storage", "data": "synthetic",
             "config": {"workload": f"{args.config}: {sc.N[0]}x{sc.N[1]}x{sc.N[2]} metavoxels x {nv}^3 voxels, "
                                    f"{len(sc.particles)} particles, {sc.width}x{sc.height}",
+                       "update_interval": update_interval,
                        "cubemap": ("R8 (8-bit like the reference's asset; LDS-resident in k_fill)" if args.cubemap == "r8" and not args.no_lds_cubemap
                                    else "R8 on the global f32 footprint table" if args.cubemap == "r8" else "f32 texels, global footprint table"),
                        "displacement_scale": sc.displacement_scale,
@@ -373,6 +407,7 @@ def main():
                        "slabs": [[a, b] for a, b in zip(info["slab_cuts"], info["slab_cuts"][1:])] if N > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),
+                       "samples_executed": int(samples), "samples_formula": int(samples_formula),
                        "work_unit": ("voxels + executed samples of the 1-GPU job (fixed for every N)" if (N == 1 or ref_units is not None)
                                      else "voxels + samples executed on all ranks (1-GPU reference job not run: see reference_frame_skipped)"),
                        "samples_executed_all_ranks": int(executed[1]),
@@ -380,7 +415,9 @@ def main():
             # absolute rates: per stage against that stage's kernel time on the slowest rank (fill = local + finish for N > 1),
             # and for the whole frame (everything incl. the exchanges)
             "fill_mvoxels_per_s": voxels / fill_t / 1e6,
-            "raymarch_msamples_per_s": samples / (smax[2] * 1e-3) / 1e6,
+            "raymarch_msamples_per_s": samples / (smax[2] * 1e-3) / 1e6,                    # executed samples (the saturation early-out skips the hidden ones)
+            "raymarch_msamples_per_s_formula": samples_formula / (smax[2] * 1e-3) / 1e6,    # SURVEY 8(d)'s count (what the CPU leg executes) over the same kernel time
+            "value_formula_units": (voxels / update_interval + samples_formula) / (dt / args.steps) / 1e6,   # the frame's work in the units of the CPU leg
             "frame_mvoxels_per_s": voxels / (dt / args.steps) / 1e6,
             "frame_msamples_per_s": samples / (dt / args.steps) / 1e6,
             "fill_frac_of_hbm_roofline": roofs["fill"]["frac"],
@@ -398,8 +435,11 @@ def main():
             "roofline_all": roofs,
         }
         if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, args.cpu_threads)
-            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"] = cpu_baseline(sc, args.cpu_threads, demo_boxes)   # (one frame WITH bin + fill; DEMO refills every 2nd frame)
+            # equal units on both sides: the CPU port executes every formula sample, so the GPU frame is credited with the same work
+            out["speedup_vs_cpu"] = out["value_formula_units"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_note"] = ("(voxels + FORMULA samples) per second, GPU frame / CPU port; in executed samples the GPU figure is `value` "
+                                          f"({out['value'] / out['cpu_baseline']['value']:.0f}x), which credits the early-out with nothing")
         print(json.dumps(out))
     eng.close()
     if multi_process:

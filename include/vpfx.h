@@ -61,7 +61,10 @@ typedef struct vp_config {
     int32_t exact_math;       /* 1: IEEE divisions in the fill kernel (bit-parity test builds)     */
     int32_t no_early_out;     /* 1: the ray-march never stops early (sample-count parity tests)    */
     int32_t reserved[3];      /* 0.  (Measurement switches: [0] = 1 keeps an R8 cube map out of LDS,
-                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey; [2] must be 0.
+                                 [1] = 1 keeps RGBA16F bricks when the ambient colour is grey.  [2]: single-device context: must be
+                                 0; fan-out context: time-out in ms of every inter-rank exchange and of every wait for one
+                                 (0 = 20 000; <= 3 600 000) -- when it expires the context ABORTS: ncclCommAbort on every local
+                                 communicator, every local rank returns VP_ERR_RCCL, every later call fails fast until vp_destroy.
                                  Any other value is refused with VP_ERR_BAD_ARG.)                    */
     /* ---- ABI 3: multi-GPU fan-out INSIDE the library ("device list", "multi-GPU fan-out is internal").
      * num_devices <= 1 and world_size == 0: one GPU (`device`), everything above.  Otherwise the context is a FAN-OUT context: the grid
@@ -93,6 +96,10 @@ typedef struct vp_config {
                                            form); default = all-to-all of screen pieces, sharded blend, gather (8x less xGMI traffic)        */
 #define VP_MULTI_UNIFORM_SLABS       4  /* equal-thickness slabs; default: balanced from the work histograms                                  */
 #define VP_MULTI_FORCE               8  /* take the fan-out path (threads, RCCL communicator, collectives) even with one rank                 */
+#define VP_MULTI_TEST_DROP_SEND     16  /* TEST HOOK (needs VP_MULTI_TEST_HOOKS + VP_MULTI_PEER_COPY): the last rank silently skips the first message it
+                                           should send -- its peers must time out, the context must abort and every call return VP_ERR_RCCL     */
+#define VP_MULTI_TEST_HOOKS 0x40000000  /* opt-in for test hooks (any context, single-device ones too): only with this bit does vp_create read the
+                                           VPFX_TEST_* environment switches (VPFX_TEST_CHAIN_TIMEOUT=1: the fill's chain watchdog test)           */
 
 /* Byte layout of one caller-side particle record (ParticleSystem.Particle[], VPR.cs:412-413).
  * Offsets are explicit because the managed struct layout is Unity-version specific. */
@@ -332,6 +339,34 @@ int  vp_plan_slabs(int32_t nz, int32_t world, const double* fill_ms, const doubl
 int  vp_blend_plan(int32_t world, const int32_t* cuts, int32_t z_boundary, int32_t* chain_out, int32_t* plan_rank, int32_t* plan_which,
                    int32_t* plan_kind, int32_t* n_plan, int32_t* straddler);
 
+/* The message schedule of the image exchange (host-only, no GPU needed): what rank `rank` of `world` sends, receives and copies, in order.
+ * The library's own fan-out executes exactly this list (csrc/multi.cpp: send / recv -> grouped ncclSend / ncclRecv or peer copies, all-gather
+ * -> ncclAllGather), and the CPU tests execute it over gloo on host buffers (tests/test_fanout_gloo.py) -- one definition of the exchange.
+ * Buffers are arrays of UNITS: one unit = one screen piece (ceil(W H / world) pixels, tiles exchange) or one whole padded image (all-gather
+ * exchange).  VP_XBUF_PRIMARY: this rank's first partial image in blend order [world units / 1 unit]; VP_XBUF_SECOND: the straddling
+ * slab's phase-B image, same shape; VP_XBUF_PIECES: [world + 1] received units, slot r = rank r's, slot world = the straddler's second;
+ * VP_XBUF_PIECE_OUT: [1] the unit this rank blends (tiles); VP_XBUF_FINAL: [world] the finished image on rank 0.
+ * phase 0 = everything before the ordered blend (the blend reads VP_XBUF_PIECES per vp_blend_plan and writes VP_XBUF_PIECE_OUT, or -- all-gather
+ * exchange, rank 0 only -- VP_XBUF_FINAL); phase 1 = after it (gather of the finished pieces on rank 0; empty for the all-gather exchange).
+ * Consecutive VP_XOP_SEND / VP_XOP_RECV entries form one batch (issued together, they complete together). */
+typedef struct vp_xop {
+    int32_t kind;                 /* VP_XOP_*                                                                         */
+    int32_t peer;                 /* SEND / RECV: the other rank; otherwise -1                                        */
+    int32_t buf, index;           /* SEND / COPY: source unit; RECV: destination unit; ALL_GATHER: buf, own unit      */
+    int32_t dst_buf, dst_index;   /* COPY: destination unit                                                           */
+} vp_xop;
+#define VP_XOP_RECV 0
+#define VP_XOP_SEND 1
+#define VP_XOP_COPY 2
+#define VP_XOP_ALL_GATHER 3       /* in-place all-gather of buf: every rank contributes unit `index` (= its rank)      */
+#define VP_XBUF_PRIMARY 0
+#define VP_XBUF_SECOND 1
+#define VP_XBUF_PIECES 2
+#define VP_XBUF_PIECE_OUT 3
+#define VP_XBUF_FINAL 4
+int  vp_exchange_plan(int32_t world, int32_t rank, int32_t straddler /* -1: none */, int32_t all_gather_exchange, int32_t phase,
+                      vp_xop* ops_out, int32_t cap, int32_t* n_out);
+
 /* ---- multi-GPU building blocks (one context per GPU, each owning a contiguous zz slab; what the fan-out is made of) ------------ */
 /* Fill split at the only cross-slab dependency, the per-column transmitted light (Fill.shader:224,250):
  *   vp_fill_local   : density/ao of the slab + slab transmittance map tau (computed with T_in = 1)
@@ -408,6 +443,12 @@ int  vp_unity_set_frame_desc(int32_t slot, const vp_unity_frame* frame);
 int  vp_unity_register_output(int32_t slot, void* d_rgba_out, float* h_rgba_out);
 /* Status of the most recent event of the slot (Unity's callback returns void) and how many events have run. */
 int  vp_unity_last_status(int32_t slot, uint64_t* events_run);
+/* Detach the slot: waits for an event of the slot that is executing right now, then forgets its frame description and outputs, so that an
+ * event Unity delivers LATER is a no-op (status VP_ERR_STATE; the event counter keeps counting).  Call it before freeing anything the frame
+ * description points to and before vp_destroy -- the render thread runs an issued event whenever it gets to it.  A host that issues one
+ * event per frame should also not touch the arrays of the description (particles, the read-back buffer) while
+ * vp_unity_last_status().events_run is behind the number of events it has issued. */
+int  vp_unity_clear_slot(int32_t slot);
 
 /* ---- parity probes / stats ------------------------------------------------------------------ */
 int  vp_get_mv_positions(vp_ctx* ctx, float* pos_out /* [Nz][Ny][Nx][3] */);

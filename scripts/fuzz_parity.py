@@ -4,6 +4,7 @@ random light depth maps and scene depth.  Every case checks: identical bin count
 ulp in fast mode), light map, RGBA <= 1e-3 and -- with the early-out off -- the oracle's sample count.
 usage: fuzz_parity.py [cases] [first_seed]"""
 import math
+import os
 import sys
 import time
 
@@ -107,7 +108,9 @@ def one_case(seed):
     assert ge.stats()["samples"] <= sg
     # every third case: the slab-sharded path (K engines on this GPU, in-process exchanges) and the literal-order kernel
     if seed % 3 == 0 and sc.N[2] >= 2:
-        from vpfx_amd import parallel as PAR, abi
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+        import slab_reference as PAR
+        from vpfx_amd import abi
         world = int(rng.integers(2, min(sc.N[2], 4) + 1))
         bounds = PAR.slab_bounds(sc.N[2], world)
         engs = []

@@ -25,7 +25,13 @@ for db in sys.argv[2:]:
     finally:
         con.close()
 SIMDS = 1024
-out = {"kernel_sources_sha": kernel_sources_sha(), "source": "rocprofv3 --pmc passes of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline` (scripts/gpu_prof_r3.sh)"}
+try:
+    _m = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_mix.json")))
+    ISA_MIX = _m["kernels"] if _m.get("kernel_sources_sha") in (None, kernel_sources_sha()) else {}
+    if not ISA_MIX: print("profiles/r04_isa_mix.json was made on other kernel sources: no valu_issue fraction (rerun scripts/isa_mix.py)", file=sys.stderr)
+except Exception:
+    ISA_MIX = {}
+out = {"kernel_sources_sha": kernel_sources_sha(), "source": "rocprofv3 --pmc passes of the bench command (scripts/gpu_prof_r4.sh)"}
 for k, c in ctr.items():
     g = lambda name: c.get(name)
     d = {"instantiation": c["instantiation"]}
@@ -33,7 +39,20 @@ for k, c in ctr.items():
     if cyc: cyc /= 8.0                          # the counter is summed over the 8 XCDs
     if g("SQ_INSTS_VALU") is not None: d["valu_wave_instructions_per_launch"] = g("SQ_INSTS_VALU")
     if g("SQ_INSTS_VALU") is not None and g("SQ_INSTS_VMEM_RD"): d["valu_per_vmem_read"] = g("SQ_INSTS_VALU") / g("SQ_INSTS_VMEM_RD")
-    if g("SQ_ACTIVE_INST_VALU") is not None and cyc: d["valu_issue_busy_fraction"] = g("SQ_ACTIVE_INST_VALU") * 4.0 / (SIMDS * cyc)   # ~1 = VALU-issue-bound
+    # VALU issue: SQ_ACTIVE_INST_VALU is NOT a busy time on gfx950 -- under the opcode probe it reads exactly 1 quad-cycle per instruction (2 for a
+    # transcendental) whatever the opcode's real issue rate (2.2-2.7 / 4.3 / 8.25 cycles per wave64 instruction per SIMD; scripts/gpu_valu_class.sh,
+    # profiles/r04_valu_class_calibration.txt), so round 3's `x 4 / SIMD-cycles` exceeded 1.  The fraction reported here prices the class
+    # counters of this run (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, _INT32, _CVT; the rest = SQ_INSTS_VALU minus those) with the average issue
+    # cycles of that class IN THIS KERNEL (loop-weighted static opcode mix of its ISA x the measured per-opcode rates: profiles/r04_isa_mix.json).
+    mix = ISA_MIX.get(c["instantiation"])
+    cls = {n: g("SQ_INSTS_VALU_" + n) for n in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")}
+    if mix and g("SQ_INSTS_VALU") is not None and all(v is not None for v in cls.values()) and cyc:
+        cls["OTHER"] = max(g("SQ_INSTS_VALU") - sum(cls.values()), 0.0)
+        need = sum(n * mix.get(k, {}).get("avg_issue_cycles", 4.3) for k, n in cls.items())
+        d["valu_issue"] = {"bound": "valu_issue", "unit": "SIMD issue cycles per launch", "achieved": need, "peak": SIMDS * cyc, "frac": need / (SIMDS * cyc),
+                           "wave_instructions_by_class": cls,
+                           "avg_issue_cycles_by_class": {k: round(mix.get(k, {}).get("avg_issue_cycles", 4.3), 3) for k in cls},
+                           "source": "class counters of this profile x profiles/r04_isa_mix.json (opcode rates: profiles/r04_valu_classes.json)"}
     if g("SQ_THREAD_CYCLES_VALU") is not None and g("SQ_ACTIVE_INST_VALU"): d["lanes_enabled_per_valu_fraction"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"): d["lds_conflict_share_of_lds_cycles"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     if g("SQ_LDS_IDX_ACTIVE") is not None and cyc: d["lds_pipe_busy_fraction"] = g("SQ_LDS_IDX_ACTIVE") / (256.0 * cyc)
@@ -42,7 +61,7 @@ for k, c in ctr.items():
     if g("TCP_TOTAL_CACHE_ACCESSES_sum") is not None and cyc: d["l1_accesses_per_cu_cycle"] = g("TCP_TOTAL_CACHE_ACCESSES_sum") / (256.0 * cyc)
     if g("SQ_WAVE_CYCLES") is not None and cyc: d["wave_cycles_x4_per_simd_cycle"] = g("SQ_WAVE_CYCLES") * 4.0 / (SIMDS * cyc)   # average waves resident per SIMD
     if cyc: d["gpu_cycles_per_launch"] = cyc
-    d["limited_by"] = "VALU issue" if d.get("valu_issue_busy_fraction", 0) >= 0.7 else "see the fractions"
+    d["limited_by"] = "VALU issue" if d.get("valu_issue", {}).get("frac", 0) >= 0.7 else "see the fractions"
     out[k] = d
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))

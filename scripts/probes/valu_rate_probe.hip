@@ -9,12 +9,13 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum { OP_FMA, OP_PKFMA, OP_MUL, OP_CUBEID, OP_CUBEMA, OP_RCP, OP_SQRT, OP_FLOOR, OP_FRACT, OP_CVTU, OP_MED3, OP_MAX, OP_CNDMASK,
-       OP_MIX, OP_DSADD, OP_DSMAX, OP_DSREAD, OP_MOVREL, OP_ALIGNBYTE, OP_CVTUB, OP_ADD, OP_SUB, OP_FMAC, OP_CMP, OP_MOV, OP_PKADD, OP_PKMUL, OP_ADDU, OP_MIN, OP_DSREADU8, OP_DSRMW, OP_CVTF16, OP_MULDEN, OP_MULNRM, OP_SUBDEN, OP_PKMULDEN, OP_FMADEN, OP_COUNT };
+       OP_MIX, OP_DSADD, OP_DSMAX, OP_DSREAD, OP_MOVREL, OP_ALIGNBYTE, OP_CVTUB, OP_ADD, OP_SUB, OP_FMAC, OP_CMP, OP_MOV, OP_PKADD, OP_PKMUL, OP_ADDU, OP_MIN, OP_DSREADU8, OP_DSRMW, OP_CVTF16, OP_MULDEN, OP_MULNRM, OP_SUBDEN, OP_PKMULDEN, OP_FMADEN, OP_MAXI, OP_AND, OP_LSHL, OP_MULU24, OP_CVTF16F32, OP_CVTI, OP_CNDS, OP_MADU24, OP_LSHLADD, OP_COUNT};
 static const char* NAMES[] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_cubeid_f32", "v_cubema_f32", "v_rcp_f32", "v_sqrt_f32", "v_floor_f32",
                               "v_fract_f32", "v_cvt_u32_f32", "v_med3_f32", "v_max_f32", "v_cndmask_b32", "v_fma_mix_f32", "ds_add_f32", "ds_max_f32",
                               "ds_read_b32", "v_mov(gpr_idx)", "v_alignbyte_b32", "v_cvt_f32_ubyte1", "v_add_f32", "v_sub_f32", "v_fmac_f32", "v_cmp_le_f32", "v_mov_b32",
                               "v_pk_add_f32", "v_pk_mul_f32", "v_add_u32", "v_min_f32", "ds_read_u8", "ds_read+add+ds_write", "v_cvt_f32_f16",
-                              "v_mul_f32 denormal*K", "v_mul_f32 normal*K (same form)", "v_sub_f32 den-den", "v_pk_mul_f32 den*K", "v_fma_f32 K*den+den"};
+                              "v_mul_f32 denormal*K", "v_mul_f32 normal*K (same form)", "v_sub_f32 den-den", "v_pk_mul_f32 den*K", "v_fma_f32 K*den+den",
+                              "v_max_i32", "v_and_b32", "v_lshlrev_b32", "v_mul_u32_u24", "v_cvt_f16_f32", "v_cvt_i32_f32", "v_cndmask_b32 (sgpr mask)", "v_mad_u32_u24", "v_lshl_add_u32"};
 
 template <int OP>
 __device__ __forceinline__ void op(float& a, f2& a2, float b, float c, unsigned lds_addr)
@@ -57,6 +58,16 @@ __device__ __forceinline__ void op(float& a, f2& a2, float b, float c, unsigned 
     if (OP == OP_MOVREL) asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
     if (OP == OP_ALIGNBYTE) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
     if (OP == OP_CVTUB) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a));
+    // round 4: integer / conversion flavours (which SQ_INSTS_VALU_* class counter each opcode lands in, and its rate; scripts/valu_class_calibration.py)
+    if (OP == OP_MAXI) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == OP_AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == OP_LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
+    if (OP == OP_MULU24) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == OP_CVTF16F32) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a));
+    if (OP == OP_CVTI) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a));
+    if (OP == OP_CNDS) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a) : "v"(b) : "s20", "s21");
+    if (OP == OP_MADU24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == OP_LSHLADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
 }
 
 template <int OP, int ILP>
@@ -127,6 +138,8 @@ int main()
     sweep<OP_ALIGNBYTE>(d_out, h); sweep<OP_CVTUB>(d_out, h);
     sweep<OP_MULDEN>(d_out, h); sweep<OP_MULNRM>(d_out, h); sweep<OP_SUBDEN>(d_out, h); sweep<OP_PKMULDEN>(d_out, h); sweep<OP_FMADEN>(d_out, h);
     sweep<OP_DSMAX>(d_out, h); sweep<OP_DSREAD>(d_out, h); sweep<OP_DSREADU8>(d_out, h); sweep<OP_DSRMW>(d_out, h);
+    sweep<OP_MAXI>(d_out, h); sweep<OP_AND>(d_out, h); sweep<OP_LSHL>(d_out, h); sweep<OP_MULU24>(d_out, h); sweep<OP_MADU24>(d_out, h); sweep<OP_LSHLADD>(d_out, h);
+    sweep<OP_CVTF16F32>(d_out, h); sweep<OP_CVTI>(d_out, h); sweep<OP_CNDS>(d_out, h);
     masks<OP_FMA>(d_out, h); masks<OP_FLOOR>(d_out, h); masks<OP_RCP>(d_out, h); masks<OP_PKFMA>(d_out, h); masks<OP_DSREAD>(d_out, h);
     return 0;
 }

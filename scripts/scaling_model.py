@@ -55,8 +55,8 @@ def frame(e, first=False):
     e.bin_resident(); e.fill(sc.fill_params()); e.raymarch_device(cam, rp, img.data_ptr())
 
 
-for world in (2, 4, 8):
-    for groups in sorted({1, 2, world}):
+for world in (2, 4, 7, 8):                # (7: the slab cut of the alternative 8-GPU plan below)
+    for groups in (sorted({1, 2, world}) if world != 7 else [1]):
         # 1. the library's own cut, chain and groups
         m = E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY, rm_groups=groups))
         m.set_frame(sc.light_to_world, sc.grid_center)
@@ -119,5 +119,46 @@ for world in (2, 4, 8):
               f"max bin+fill_local {max(x['bin'] + x['fill_local'] for x in rows.values()):.2f} finish {max(x['finish'] for x in rows.values()):.2f} max finish+rm {max(x['finish'] + x['rm'] for x in rows.values()):.2f} "
               f"rm per group {[round(x, 3) for x in rm_groups]} (max single {max(x['rm'] for x in rows.values()):.3f}); exchanges {1e3 * (t_tau + (G - 1) * t_hop + t_img):.2f}; "
               f"samples {sum(x['samples'] for x in rows.values()) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M; fan-out image err {err:.1e}", flush=True)
-os.makedirs("gpurun_out/r3", exist_ok=True)
-json.dump(out, open(f"gpurun_out/r3/scaling_model_{name}_{cube}.json", "w"), indent=1)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# ONE alternative plan for 8 GPUs: the front slab -- the one that holds most of the ray-march when light and camera are on
+# the same side -- is FILLED ON TWO RANKS (replicated: each fills the whole slab) which split its SCREEN, so that its ray-march halves; the other
+# six ranks share the remaining slices.  Seven distinct slabs = the library's cut for world 7 (measured above); the two halves of the front
+# slab's ray-march are measured for real: a scene-depth buffer of 0 on the other half of the screen rejects every metavoxel there (ZTest Less,
+# RM.shader:14), the split column halves the executed samples (from the samples-per-ray view).
+p7 = out["predictions"]["7gpu_1groups"]
+cuts7 = p7["slab_cuts"]
+e = E.Engine(sc.config(device=0, slab=(cuts7[0], cuts7[1])))
+e.set_frame(sc.light_to_world, sc.grid_center)
+e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+e.bin_resident(); e.fill(sc.fill_params())
+rq = sc.raymarch_params(); rq.flags = abi.VP_RM_SHOW_RAY_SAMPLES
+per_col = e.raymarch(cam, rq)[..., 0].astype(np.float64).sum(axis=0)
+split = int(np.searchsorted(np.cumsum(per_col), per_col.sum() / 2.0))
+halves = []
+for side in (0, 1):
+    depth = np.full((sc.height, sc.width), 3.0e38, dtype=np.float32)
+    if side == 0: depth[:, split:] = 0.0
+    else: depth[:, :split] = 0.0
+    rh = sc.raymarch_params(); rh.scene_depth = depth.ctypes.data_as(abi.c_float_p)
+    over, under = torch.empty_like(img), torch.empty_like(img)
+    for _ in range(3):
+        e.raymarch_partial_handoff_device(cam, rh, over.data_ptr(), under.data_ptr(), 0, 0, 0, 0)
+    e.sync()
+    halves.append(dict(rm=e.last_kernel_ms(2), samples=e.stats()["samples"]))
+e.close()
+rows7 = p7["per_rank"]
+fill_max = max(x["bin"] + x["fill_local"] for x in rows7)
+after7 = max([x["finish"] + x["rm"] for x in rows7[1:]] + [h["rm"] for h in halves])
+piece8 = npix * 16 / 8
+t_alt = (fill_max + after7) * 1e-3 + (LAT + lm_bytes / LINK1) + 2 * (LAT + piece8 / LINK1) + 0.02e-3
+base8 = out["predictions"]["8gpu_1groups"]["predicted_ms_per_step"]
+out["alternative_8gpu_front_slab_on_two_ranks"] = {
+    "slab_cuts_7": cuts7, "screen_split_column": split, "front_halves": halves, "front_slab_whole": rows7[0],
+    "max_bin_fill_local_ms": fill_max, "max_after_allgather_ms": after7, "predicted_ms_per_step": t_alt * 1e3,
+    "baseline_8_slabs_ms_per_step": base8, "beats_baseline": bool(t_alt * 1e3 < base8)}
+print(f"ALTERNATIVE at 8 GPUs -- front slab {cuts7[:2]} filled on two ranks, screen split at column {split}: halves' ray-march "
+      f"{halves[0]['rm']:.3f} / {halves[1]['rm']:.3f} ms (whole: {rows7[0]['rm']:.3f}), max bin+fill_local {fill_max:.2f} (8 slabs: "
+      f"{max(x['bin'] + x['fill_local'] for x in out['predictions']['8gpu_1groups']['per_rank']):.2f}), max after the all-gather {after7:.2f}: "
+      f"predicted {t_alt * 1e3:.2f} ms/step vs {base8:.2f} for eight slabs -> {'BEATS' if t_alt * 1e3 < base8 else 'does NOT beat'} it", flush=True)
+os.makedirs("gpurun_out/r4_scaling", exist_ok=True)
+json.dump(out, open(f"gpurun_out/r4_scaling/scaling_model_{name}_{cube}.json", "w"), indent=1)

@@ -310,51 +310,49 @@ def test_displacement_scale_one_never_flips_a_voxel_across_the_smoothstep_jump()
             np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=3e-4, atol=1e-9)   # (a flipped voxel would show as 4 %)
 
 
-def test_samples_per_ray_view_and_wave_coherent_traversal(monkeypatch):
+def test_samples_per_ray_view_and_the_per_call_early_out_switch():
     """VP_RM_SHOW_RAY_SAMPLES (perf view): every pixel = the samples its ray executed, early-out left on; their sum is the frame's sample count.
-    k_raymarch_flat (VPFX_RM_FLAT=1 at vp_create: the wave-coherent traversal, an A/B variant -- slower) must produce the
-    nested kernel's frame bit for bit with the same executed samples, whole grid and slab, grey and RGBA bricks, cameras outside and inside."""
+    VP_RM_NO_EARLY_OUT (one call marches every lattice sample of SURVEY 8(d)'s formula on the resident bricks): the count equals the oracle's,
+    which a context created with no_early_out also executes; the image is the default frame's up to rounding; the next default call is
+    unaffected.  (k_raymarch_flat, the wave-coherent A/B traversal this test also covered until round 3, is compiled into VPFX_AB builds only.)"""
     from vpfx_amd import abi
-    import torch
+    from oracle import oracle as O
     for ambient, cam_pos in (((0.2, 0.2, 0.2), None), ((0.1, 0.3, 0.2), (0.5, 0.3, 1.0)), ((0.2, 0.2, 0.2), (2.0, 9.0, 1.0))):
         sc = S.make_scene("C1", cubemap="r8")
         sc.ambient = ambient
         if cam_pos is not None:
             sc.set_camera(cam_pos)
         cam, rp = sc.camera(), sc.raymarch_params()
-        engs = []
-        for flat in (False, True):
-            if flat:
-                monkeypatch.setenv("VPFX_RM_FLAT", "1")
-            g = E.Engine(sc.config())
-            s = E.Engine(sc.config(slab=(2, 6)))
-            monkeypatch.delenv("VPFX_RM_FLAT", raising=False)
-            for x in (g, s):
-                x.set_frame(sc.light_to_world, sc.grid_center)
-                x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
-                x.fill(sc.fill_params())
-            engs.append((g, s))
-        (g0, s0), (g1, s1) = engs
-        i0, i1 = g0.raymarch(cam, rp), g1.raymarch(cam, rp)
-        np.testing.assert_array_equal(i0, i1)
-        assert g0.stats()["samples"] == g1.stats()["samples"] and g0.stats()["bricks_sampled"] == g1.stats()["bricks_sampled"]
-        parts = []
-        for x in (s0, s1):
-            over, under = (torch.empty((sc.height, sc.width, 4), device="cuda") for _ in range(2))
-            x.raymarch_partial_device(cam, rp, over.data_ptr(), under.data_ptr())
-            x.sync()
-            parts.append((over.cpu().numpy(), under.cpu().numpy(), x.stats()["samples"], x.zsamples()))
-        np.testing.assert_array_equal(parts[0][0], parts[1][0]); np.testing.assert_array_equal(parts[0][1], parts[1][1])
-        assert parts[0][2] == parts[1][2] and np.array_equal(parts[0][3], parts[1][3])
+        g0 = E.Engine(sc.config())
+        gall = E.Engine(sc.config(), early_out=False)
+        o = O.Oracle(sc.config())
+        for x in (g0, gall, o):
+            x.set_frame(sc.light_to_world, sc.grid_center)
+            x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+            x.fill(sc.fill_params())
+        i0 = g0.raymarch(cam, rp)
+        executed = g0.stats()["samples"]
+        o.raymarch(cam, rp)
+        formula = o.stats()["samples"]
         rq = sc.raymarch_params()
+        rq.flags = abi.VP_RM_NO_EARLY_OUT
+        i_all = g0.raymarch(cam, rq)
+        assert g0.stats()["samples"] == formula >= executed
+        gall.raymarch(cam, rp)
+        assert gall.stats()["samples"] == formula
+        assert np.abs(i_all - i0).max() <= 2e-6
+        i1 = g0.raymarch(cam, rp)                                      # the switch is per call
+        np.testing.assert_array_equal(i0, i1)
+        assert g0.stats()["samples"] == executed
         rq.flags = abi.VP_RM_SHOW_RAY_SAMPLES
         n = g0.raymarch(cam, rq)
         assert np.all(n[..., 3] == 1.0) and np.array_equal(n[..., 0], n[..., 2])
         assert int(n[..., 0].astype(np.int64).sum()) == g0.stats()["samples"]            # the view's own frame
         if cam_pos is None:        # all phase B: the flag kernel's literal order stops rays exactly where the default kernel does
-            assert g0.stats()["samples"] == g1.stats()["samples"]
-        for x in (g0, s0, g1, s1):
+            assert g0.stats()["samples"] == executed
+        for x in (g0, gall):
             x.close()
+        o.close()
 
 
 def test_async_raymarch_overlaps_the_image_copy_with_the_next_frame():

@@ -106,12 +106,21 @@ def test_tag_range_wraps_after_many_launches_on_a_deep_grid():
 
 
 def test_watchdog_reports_a_hand_off_that_never_arrives(monkeypatch):
-    """Test hook VPFX_TEST_CHAIN_TIMEOUT=1 (environment, read by vp_create; not reachable through the ABI structs): units await tags nobody
+    """Test hook VPFX_TEST_CHAIN_TIMEOUT=1 (environment, read by vp_create only when vp_config.multi_flags carries VP_MULTI_TEST_HOOKS): units await tags nobody
     writes and give up after a few polls.  The fill then completes -- no hung GPU --, the next synchronising call returns an error, the fill
     counts as not done (a ray-march must not composite its bricks), and the context stays usable."""
     sc = S.make_scene("C1", cubemap="r8")
     monkeypatch.setenv("VPFX_TEST_CHAIN_TIMEOUT", "1")
-    g = E.Engine(sc.config())
+    # without the opt-in bit in vp_config the environment is never read (a stray variable must not break a production context)
+    plain = E.Engine(sc.config())
+    plain.set_frame(sc.light_to_world, sc.grid_center)
+    plain.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    plain.fill(sc.fill_params())
+    plain.sync()
+    plain.close()
+    cfg = sc.config()
+    cfg.multi_flags = abi.VP_MULTI_TEST_HOOKS
+    g = E.Engine(cfg)
     monkeypatch.delenv("VPFX_TEST_CHAIN_TIMEOUT")
     g.set_frame(sc.light_to_world, sc.grid_center)
     g.bin(sc.particles, sc.layout, sc.psys_local_to_world)

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from vpfx_amd import abi, engine as E, parallel as PAR, scene as S
+from vpfx_amd import abi, engine as E, scene as S
+import slab_reference as PAR
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu

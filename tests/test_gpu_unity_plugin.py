@@ -80,6 +80,15 @@ def test_render_event_runs_the_frame_on_another_thread(fanout):
     assert L.vp_unity_last_status(slot, None) == 0
     assert np.abs(host - ref2).max() <= tol
     assert L.vp_unity_set_frame_desc(99, C.byref(frame2)) == abi.VP_ERR_BAD_ARG
+    # teardown order of a host: detach the slot BEFORE freeing the arrays and the context; an event Unity delivers afterwards is a
+    # no-op -- it must neither touch the old buffer nor the destroyed context -- and the counter keeps counting
+    L.vp_unity_last_status(slot, C.byref(ev))
+    before = ev.value
+    assert L.vp_unity_clear_slot(slot) == 0 and L.vp_unity_clear_slot(99) == abi.VP_ERR_BAD_ARG
+    host[...] = -7.0
+    _issue_plugin_event(fn, slot)
+    assert L.vp_unity_last_status(slot, C.byref(ev)) == abi.VP_ERR_STATE and ev.value == before + 1
+    assert np.all(host == -7.0)
     L.UnityPluginUnload()
     assert L.vp_unity_last_status(slot, C.byref(ev)) == abi.VP_ERR_STATE and ev.value == 0          # unloading forgets every slot
     eng.close(); direct.close()

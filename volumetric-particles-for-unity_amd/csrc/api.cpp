@@ -256,9 +256,14 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
     if (!c) return vp_fail(nullptr, VP_ERR_OOM, "vp_create: host allocation failed");
     c->cfg = *cfg;
     c->device = dev;
-    { const char* hook = getenv("VPFX_TEST_CHAIN_TIMEOUT"); c->test_chain_timeout = hook && hook[0] == '1'; }
+    // test hooks are honoured only by contexts that opt in through vp_config (VP_MULTI_TEST_HOOKS): a stray environment variable never
+    // changes what a production context does
+    if (cfg->multi_flags & VP_MULTI_TEST_HOOKS) { const char* hook = getenv("VPFX_TEST_CHAIN_TIMEOUT"); c->test_chain_timeout = hook && hook[0] == '1'; }
+#if VPFX_AB    // measurement switches of A/B builds (make EXTRA=-DVPFX_AB=1); the shipped library never reads them
     { const char* sw = getenv("VPFX_NO_ZPROFILE"); c->no_zprofile = sw && sw[0] == '1'; }
     { const char* sw = getenv("VPFX_RM_FLAT"); c->rm_flat = sw && sw[0] == '1'; }
+    { const char* sw = getenv("VPFX_RM_XCD_AFFINE"); c->rm_xcd_affine = sw && sw[0] == '1'; }
+#endif
     c->n3 = (size_t)cfg->num_mv[0] * cfg->num_mv[1] * cfg->num_mv[2];
     // identity frame until vp_set_frame
     memset(c->L, 0, sizeof c->L); c->L[0] = c->L[5] = c->L[10] = c->L[15] = 1.f;
@@ -280,8 +285,29 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
         (rc = dev_alloc(c, &c->d_zsamples, (size_t)VPFX_ZPROF_COPIES * cfg->num_mv[2])) ||
-        (rc = dev_alloc(c, &c->d_cam_rows, 12)) || (rc = dev_alloc(c, &c->d_tile_order, 2 * ((size_t)rm_num_super_tiles(cfg->width, cfg->height) + 8))))
+        (rc = dev_alloc(c, &c->d_cam_rows, 12)) || (rc = dev_alloc(c, &c->d_tile_order, (size_t)rm_order_ints(rm_num_super_tiles(cfg->width, cfg->height)) + rm_num_super_tiles(cfg->width, cfg->height) + 8)))
         return fail(rc);
+#if VPFX_AB
+    {
+        // Hilbert order of the super-tile grid (k_tile_regions cuts it into one compact screen region per XCD): cells of the enclosing
+        // 2^k x 2^k square in curve order, those outside the grid skipped
+        const int sgx = rm_super_tiles_x(cfg->width), sgy = rm_super_tiles_y(cfg->height), ns = sgx * sgy;
+        int side = 1; while (side < sgx || side < sgy) side <<= 1;
+        std::vector<int> curve; curve.reserve(ns);
+        for (long long d = 0; d < (long long)side * side; ++d) {
+            long long tt = d; int x = 0, y = 0;
+            for (int sdim = 1; sdim < side; sdim <<= 1) {
+                const int rx = 1 & (int)(tt / 2), ry = 1 & ((int)tt ^ rx);
+                if (ry == 0) { if (rx == 1) { x = sdim - 1 - x; y = sdim - 1 - y; } const int tmp = x; x = y; y = tmp; }
+                x += sdim * rx; y += sdim * ry; tt /= 4;
+            }
+            if (x < sgx && y < sgy) curve.push_back(y * sgx + x);
+        }
+        if ((int)curve.size() == ns && (rc = dev_alloc(c, &c->d_tile_curve, (size_t)ns)) == VP_OK) {
+            if (hipMemcpy(c->d_tile_curve, curve.data(), (size_t)ns * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return fail(VP_ERR_HIP); }
+        } else if (rc) return fail(rc);
+    }
+#endif
     if (hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_chain_err, c->h_chain_err, 0) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(VP_ERR_HIP); }
     *c->h_chain_err = 0;
@@ -307,7 +333,7 @@ void vp_destroy_single(vp_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
-                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo, c->d_occmask};
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_tile_curve, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo, c->d_occmask};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -335,6 +361,9 @@ VP_EXPORT int vp_unpin_host_buffer(vp_ctx* c, void* ptr)
     if (c->multi) { int rcm = multi_sync(c); if (rcm) return rcm; VP_HIP(hipHostUnregister(ptr)); return VP_OK; }
     int rc = ensure_device(c); if (rc) return rc;
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
+    // a vp_raymarch_async read-back runs on the copy stream, which the caller's stream does not wait for: the buffer must not lose its page
+    // lock (and be freed by the caller) under a copy in flight
+    if (c->image_copy_pending) { VP_HIP(hipEventSynchronize(c->ev_image_copied)); c->image_copy_pending = false; }
     VP_HIP(hipHostUnregister(ptr));
     return VP_OK;
 }
@@ -710,7 +739,7 @@ VP_EXPORT int vp_read_zsamples(vp_ctx* c, int64_t* samples_per_z)
     long long* tmp = (long long*)malloc((size_t)c->g.Nz * sizeof(long long));
     if (!tmp) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
     rc = api_read_zsamples(c, tmp, true);
-    for (int i = 0; i < c->g.Nz; ++i) samples_per_z[i] = tmp[i];
+    if (!rc) for (int i = 0; i < c->g.Nz; ++i) samples_per_z[i] = tmp[i];        // (a failed read leaves the caller's buffer alone)
     free(tmp);
     return rc;
 }
@@ -940,8 +969,10 @@ VP_EXPORT int vp_get_stats(vp_ctx* c, vp_stats* st)
     unsigned long long s = 0;
     VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));
     st->samples = (int64_t)s;
-    if (c->d_brick_hit && c->h_meta.occupied > 0 && c->ev_valid[2]) {
-        const int n = c->h_meta.occupied;
+    if (c->d_brick_hit && c->brick_hit_n > 0 && c->ev_valid[2]) {
+        // the hit flags of the LAST ray-march: its own metavoxel count, not the current bin's (a slab re-cut or a re-bin since then may have
+        // changed the occupied count beyond what the flag array holds: found by the fan-out re-cut test once the profile survived, round 4)
+        const int n = c->brick_hit_n;
         int* h = (int*)malloc((size_t)n * sizeof(int));
         if (!h) return vp_fail(c, VP_ERR_OOM, "host allocation failed");
         hipError_t e = hipMemcpy(h, c->d_brick_hit, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
@@ -973,6 +1004,16 @@ VP_EXPORT int vp_plan_slabs(int32_t nz, int32_t world, const double* fill_ms, co
         return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_plan_slabs: %d ranks for %d z-slices (at most one rank per slice, <= %d)", world, nz, VP_MAX_RANKS);
     hl_plan_slabs(nz, world, fill_ms, rm_ms, rm_groups, cuts_out);
     return VP_OK;
+}
+
+VP_EXPORT int vp_exchange_plan(int32_t world, int32_t rank, int32_t straddler, int32_t all_gather_exchange, int32_t phase, vp_xop* ops_out,
+                               int32_t cap, int32_t* n_out)
+{
+    if (world < 1 || world > VP_MAX_RANKS || rank < 0 || rank >= world || straddler < -1 || straddler >= world || (phase != 0 && phase != 1) ||
+        !n_out || (cap > 0 && !ops_out) || cap < 0)
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_exchange_plan: bad argument");
+    *n_out = hl_exchange_plan(world, rank, straddler, all_gather_exchange ? 1 : 0, phase, ops_out, cap);
+    return *n_out <= cap ? VP_OK : vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_exchange_plan: %d operations, room for %d", *n_out, cap);
 }
 
 VP_EXPORT int vp_blend_plan(int32_t world, const int32_t* cuts, int32_t z_boundary, int32_t* chain_out, int32_t* plan_rank, int32_t* plan_which,

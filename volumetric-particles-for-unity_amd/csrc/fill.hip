@@ -34,14 +34,11 @@
 #endif
 #define VPFX_STR2(x) #x
 #define VPFX_STR(x) VPFX_STR2(x)
-// A/B: fetch the bilinear quad as TWO 16-bit reads (x-adjacent texels are adjacent bytes; every other address is odd: LDS takes
-// unaligned 16-bit reads) instead of four byte reads, converted with v_cvt_f32_ubyte0/1 from the same register.  Halves the LDS
-// instructions (and their 3-4-way bank conflicts); the VALU count is unchanged.
-#ifndef VPFX_LDS_U16
-#define VPFX_LDS_U16 0
-#endif
 #ifndef VPFX_PROBE
-#define VPFX_PROBE 0
+#define VPFX_PROBE 0              // what-if / phase-timer builds (scripts/fill_phase_profile.py, profiles/r03_fill_whatif_C3_r8.txt): A/B builds only
+#endif
+#if VPFX_PROBE && !VPFX_AB
+#error "VPFX_PROBE builds produce wrong bricks on purpose: make EXTRA='-DVPFX_AB=1 -DVPFX_PROBE=n'"
 #endif
 #if VPFX_PROBE == 9
 // in-kernel phase timer (profiling builds only, scripts/fill_phase_profile.py): wave-cycles by phase, summed over all waves
@@ -56,7 +53,7 @@ extern "C" __attribute__((visibility("default"))) int vpfx_probe_read(unsigned l
 #else
 #define VPFX_TICK(ph) do { } while (0)
 #endif
-#define VPFX_LDS_READS (VPFX_LDS_U16 ? 2 : 4)      // LDS instructions per slice (lgkmcnt bookkeeping)
+#define VPFX_LDS_READS 4          // LDS instructions per slice (lgkmcnt bookkeeping).  (Two unaligned ds_read_u16 instead: 8.6 ms)
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
 #endif
@@ -113,14 +110,9 @@ __device__ __forceinline__ void wait_vm_dyn(int i, f32x4& q)
 // slice loop's instructions); with the arrays pinned to fixed registers the update is the two arithmetic instructions themselves, issued
 // inside ONE indexing window with source-0 and destination both relative:  v_add_f32 v[0+s], v[0+s], den ; v_max_i32 v[32+s], v[32+s], net
 // (ao and net are >= 0, so the integer max of the bit patterns is the float max; the exec mask restricts both to the covered lanes).
-// A/B switch for the north_star's "scattered into LDS-resident voxel tiles" (SURVEY section 7): 1 / 2 keep the wave's (density, ao)
-// tile -- CH slices x 64 columns x 2 floats = 16 KB -- in LDS instead of registers and scatter into it particle by particle (1:
-// read + add + write, deterministic order; 2: ds_add_f32, the LDS float atomic); 0 (product) = register arrays.  Global-table
-// kernel only (the LDS cube map leaves no room for tiles).  Measured at C3: see DESIGN.md section 10.
-#ifndef VPFX_FILL_LDS_TILE
-#define VPFX_FILL_LDS_TILE 0
-#endif
-
+// (The north_star's "scattered into LDS-resident voxel tiles" was built and measured in round 2 -- the wave's (density, ao) tile in LDS with
+// read-add-write 4.84 ms, with ds_add_f32 9.14 ms, against 4.66 ms for these register arrays, DESIGN.md 10 -- and removed from the source in
+// round 4; the LDS holds the cube map instead.)
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int CH> struct AccArr;
@@ -382,7 +374,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
     constexpr int PIPE = TAB == 0 ? VPFX_FILL_PIPE : VPFX_FILL_PIPE_LDS;   // footprint loads in flight per wave
     static_assert(TAB == 0 || !EXACT, "the LDS (R8) path is default-math only: EXACT keeps the oracle's f32 table arithmetic");
     const float lds_bias = (float)(f.lds_pitch + 1) + (float)lds_base;
-    const float Dk = TAB == 0 ? f.D : (VPFX_BYTE_DENORM && !VPFX_LDS_U16) ? f.D_over_255 * 8388608.0f /* 2^23: cube_shade<BYTES> */ : f.D_over_255;
+    const float Dk = TAB == 0 ? f.D : VPFX_BYTE_DENORM ? f.D_over_255 * 8388608.0f /* 2^23: cube_shade<BYTES> */ : f.D_over_255;
     const int LW = g.Nx * NV;
     const size_t lmi = (size_t)(py + yy * NV) * LW + (px + xx * NV);
 
@@ -426,17 +418,8 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
         uint32_t prev_texel = 0;                          // grey z-pair bricks: the previous slice's texel of this column
 #pragma unroll 1
         for (int c0 = 0; c0 < NV; c0 += CH) {
-#if VPFX_FILL_LDS_TILE
-            extern __shared__ float lds_tile_all[];                                      // [wave][2][CH][64]
-            float* lds_dens = lds_tile_all + (threadIdx.x >> 6) * (2 * CH * 64) + lane;
-            float* lds_ao = lds_dens + CH * 64;
-#pragma unroll
-            for (int s = 0; s < CH; ++s) { lds_dens[s * 64] = 0.f; lds_ao[s * 64] = 0.f; }
-            struct { float* p; __device__ float operator[](int s) const { return p[s * 64]; } } dens{lds_dens}, ao{lds_ao};
-#else
             typename AccArr<CH>::type dens, ao;
             AccArr<CH>::clear(dens, ao);                                                 // "clear it"  :178-181
-#endif
 
             // Vectorised pre-cull: 64 particles of the MV's list at a time, one per lane, sphere vs. this wave's
             // 8x8-column x CH-slice box in voxel units (conservative); survivors are then taken in list order
@@ -520,28 +503,17 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q) : "v"(off), "s"(p_cubequads) : "memory");
                     } else if constexpr (TAB == 1) {
                         const unsigned off = qi;   // every lane reads: any direction addresses inside the table (a select for the lanes without a covered voxel cost more)
-#if VPFX_LDS_U16
-                        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:" VPFX_STR(VPFX_LDS_PITCH_128)
-                                     : "=&v"(q.a), "=&v"(q.b) : "v"(off) : "memory");
-                        q.c = q.d = 0;
-#else
 #if VPFX_PROBE == 2
                         q.a = q.b = q.c = q.d = off & 255u; asm volatile("" : "+v"(q.a), "+v"(q.b), "+v"(q.c), "+v"(q.d));
 #else
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %4 offset:" VPFX_STR(VPFX_LDS_PITCH_128) "+1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off) : "memory");
 #endif
-#endif
                     } else {
                         const unsigned off = hit ? qi : lds_base;
                         const unsigned off2 = off + (unsigned)f.lds_pitch;                // the row below
-#if VPFX_LDS_U16
-                        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3" : "=&v"(q.a), "=&v"(q.b) : "v"(off), "v"(off2) : "memory");
-                        q.c = q.d = 0;
-#else
                         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %5\n\tds_read_u8 %2, %4 offset:1\n\tds_read_u8 %3, %5 offset:1"
                                      : "=&v"(q.a), "=&v"(q.b), "=&v"(q.c), "=&v"(q.d) : "v"(off), "v"(off2) : "memory");
-#endif
                     }
                 };
                 auto stage2 = [&](int s, float tx, float ty, float d2, bool hit, const Q& q) {
@@ -549,9 +521,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         float den, net;
                         float4 qf;
                         if constexpr (TAB == 0) qf = make_float4(q[0], q[1], q[2], q[3]);
-#if VPFX_LDS_U16
-                        else qf = make_float4((float)(q.a & 0xffu), (float)(q.b & 0xffu), (float)((q.a >> 8) & 0xffu), (float)((q.b >> 8) & 0xffu));   // v_cvt_f32_ubyte0 / 1
-#elif VPFX_BYTE_DENORM
+#if VPFX_BYTE_DENORM
                         else qf = make_float4(__uint_as_float(q.a), __uint_as_float(q.b), __uint_as_float(q.c), __uint_as_float(q.d));   // the bytes as denormals
 #else
                         else qf = make_float4((float)q.a, (float)q.b, (float)q.c, (float)q.d);   // bytes 0..255; 1/255 is folded into Dk
@@ -559,17 +529,9 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
 #if VPFX_PROBE == 1          // what-if timing probes (wrong results): 1 = no shading, 2 = no LDS reads, 3 = no cube addressing
                         den = tx + qf.x; net = ty + qf.y + qf.z + qf.w;
 #else
-                        cube_shade<EXACT, DONE, TAB != 0 && VPFX_BYTE_DENORM && !VPFX_LDS_U16>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
+                        cube_shade<EXACT, DONE, TAB != 0 && VPFX_BYTE_DENORM>(f, one_minus_D, qf, tx, ty, d2, opacity, den, net, Dk, smooth_c1);
 #endif
-#if VPFX_FILL_LDS_TILE == 1
-                        lds_dens[s * 64] += den;                                         // ds_read_b32, v_add_f32, ds_write_b32
-                        atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));   // ds_max_i32
-#elif VPFX_FILL_LDS_TILE == 2
-                        atomicAdd(lds_dens + s * 64, den);                               // ds_add_f32
-                        atomicMax(reinterpret_cast<int*>(lds_ao + s * 64), __float_as_int(net));
-#else
                         AccArr<CH>::add_max(dens, ao, s, den, net);                      // :200-201
-#endif
                     }
                 };
                 // Slices are processed in groups of 2*D (D = loads in flight) with D register sets; inside a group nothing in
@@ -1011,7 +973,7 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, int math)
     if (c->h_meta.occupied == 0) return VP_OK;
     const dim3 grid(c->h_meta.occupied * TPM);
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
-    const int tl = VPFX_FILL_LDS_TILE ? 4 * 2 * (NV < 32 ? NV : 32) * 64 * (int)sizeof(float) : 0;    // A/B variant: the four waves' (density, ao) tiles
+    const int tl = 0;
     return math == 1 ? launch_fill_chain<NV, 1>(c, mode, P, ch, grid, tl) : math == 2 ? launch_fill_chain<NV, 2>(c, mode, P, ch, grid, tl)
                                                                                      : launch_fill_chain<NV, 0>(c, mode, P, ch, grid, tl);
 }

@@ -6,6 +6,7 @@
 // fp32 with the operation order of the arithmetic spec; no contraction.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -206,6 +207,20 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
     // line, so consecutive lanes should step along the SCREEN axis on which grid x changes fastest: screen x normally, screen y when the
     // view is rolled (d grid-x / d camera-y dominates).  Scheduling only; the image does not depend on it.
     k->lane_transpose = std::fabs(k->c2g[1]) > std::fabs(k->c2g[0]) ? 1 : 0;
+    // Pixel block of a ray-march wave (k_raymarch): 8 x 8 while a pixel step is about a texel or less (neighbouring rays share texels and
+    // lines: the compact bundle wins, C3: 0.945 vs 0.972 ms), 16 x 4 once the lattice is sparser than the texels -- then nothing a wave
+    // fetches is reused, the kernel runs at the memory side's pace and what counts is the lines per wave-sample, ~ rows x lines per row
+    // (C5, 1.7 texels per pixel: 8.87 -> 7.57 ms, L2->fabric reads 58.7 -> 45.1 GB; 32 x 2 no better).  Texels per pixel at the grid centre:
+    {
+        const float dxc = g.gc[0] - cam->cam_pos[0], dyc = g.gc[1] - cam->cam_pos[1], dzc = g.gc[2] - cam->cam_pos[2];
+        const float dist = std::sqrt(dxc * dxc + dyc * dyc + dzc * dzc);
+        const float pixel = 2.0f * dist * (float)std::tan((double)cam->fov_y * 0.5) / (float)k->H;      // world size of a pixel there
+        const float texel = g.s / (float)(g.nv - 2 * g.b);
+        k->wave_lx = pixel > 1.25f * texel ? 4 : 3;
+    }
+#if VPFX_AB
+    if (const char* e = std::getenv("VPFX_RM_WAVE_LX")) { const int v = std::atoi(e); if (v >= 3 && v <= 5) k->wave_lx = v; }
+#endif
     k->texScale = (float)(g.nv - 2 * g.b);      // tc = (p + 0.5)(1 - 2b/nv) + b/nv; texel = tc*nv - 0.5   RM.shader:255-258
     k->texBias = (float)g.b - 0.5f;
     k->inv_soft = 1.0f / (float)rp->soft_distance;                           // rcp(_SoftDistance)       RM.shader:269
@@ -325,7 +340,10 @@ void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms
     for (int z = 0; z < nz; ++z) { Fv[z] = fill_ms ? fill_ms[z] : 0.0; Rv[z] = rm_ms ? rm_ms[z] : 0.0; }
     for (double a : alphas) {
         if (a == -2.0) {
-            (void)two_maxima_partition(nz, world, Fv, Rv, VPFX_FINISH_SHARE, cand.data());   // the exact optimum for one group
+            // the exact optimum for one group: nz^2 / 2 bounds x world x nz^2 steps -- 4 M at nz = 32, 34 M at 64, over half a billion at 128:
+            // above 64 slices the frame path keeps to the alpha candidates
+            if (nz > 64) continue;
+            (void)two_maxima_partition(nz, world, Fv, Rv, VPFX_FINISH_SHARE, cand.data());
         } else {
             for (int z = 0; z < nz; ++z) w[z] = a < 0.0 ? Rv[z] : Fv[z] + a * Rv[z];
             min_max_partition(nz, world, w, cand.data());
@@ -372,3 +390,47 @@ int hl_blend_plan(int world, const int* cuts, int zb, int* chain, int* plan_rank
     if (straddler) *straddler = strad;
     return n;
 }
+
+// The message schedule of the image exchange (vp_exchange_plan, include/vpfx.h): ONE definition, executed by multi.cpp on the GPUs and by the
+// CPU tests over gloo.  tiles: all-to-all of screen pieces (+ the straddler's second image scattered) -> sharded blend -> gather on rank 0;
+// all-gather (the north-star form): one all-gather of whole partial images (+ the straddler's second image to rank 0) -> blend on rank 0.
+int hl_exchange_plan(int world, int rank, int strad, int all_gather, int phase, vp_xop* ops, int cap)
+{
+    int n = 0;
+    auto put = [&](int kind, int peer, int buf, int index, int dbuf = -1, int dindex = -1) {
+        if (n < cap) ops[n] = vp_xop{kind, peer, buf, index, dbuf, dindex};
+        ++n;
+    };
+    if (!all_gather) {
+        if (phase == 0) {
+            for (int j = 0; j < world; ++j)
+                if (j != rank) {
+                    put(VP_XOP_RECV, j, VP_XBUF_PIECES, j);
+                    put(VP_XOP_SEND, j, VP_XBUF_PRIMARY, j);
+                }
+            if (strad >= 0) {
+                if (rank == strad) { for (int j = 0; j < world; ++j) if (j != rank) put(VP_XOP_SEND, j, VP_XBUF_SECOND, j); }
+                else put(VP_XOP_RECV, strad, VP_XBUF_PIECES, world);
+            }
+            put(VP_XOP_COPY, -1, VP_XBUF_PRIMARY, rank, VP_XBUF_PIECES, rank);
+            if (rank == strad) put(VP_XOP_COPY, -1, VP_XBUF_SECOND, rank, VP_XBUF_PIECES, world);
+        } else {
+            if (rank == 0) {
+                for (int j = 1; j < world; ++j) put(VP_XOP_RECV, j, VP_XBUF_FINAL, j);
+                put(VP_XOP_COPY, -1, VP_XBUF_PIECE_OUT, 0, VP_XBUF_FINAL, 0);
+            } else {
+                put(VP_XOP_SEND, 0, VP_XBUF_PIECE_OUT, 0);
+            }
+        }
+    } else if (phase == 0) {
+        put(VP_XOP_COPY, -1, VP_XBUF_PRIMARY, 0, VP_XBUF_PIECES, rank);
+        put(VP_XOP_ALL_GATHER, -1, VP_XBUF_PIECES, rank);
+        if (strad > 0) {
+            if (rank == strad) put(VP_XOP_SEND, 0, VP_XBUF_SECOND, 0);
+            else if (rank == 0) put(VP_XOP_RECV, strad, VP_XBUF_PIECES, world);
+        }
+        if (rank == 0 && strad == 0) put(VP_XOP_COPY, -1, VP_XBUF_SECOND, 0, VP_XBUF_PIECES, world);
+    }
+    return n;
+}
+

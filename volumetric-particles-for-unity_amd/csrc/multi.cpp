@@ -28,6 +28,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +66,8 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;                 // optional (failure handling): absent -> no abort, time-outs still report
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
 
     bool load()
     {
@@ -83,6 +87,10 @@ struct Rccl {
         sym(CommDestroy, "ncclCommDestroy"); sym(CommCount, "ncclCommCount"); sym(AllGather, "ncclAllGather");
         sym(Send, "ncclSend"); sym(Recv, "ncclRecv"); sym(GroupStart, "ncclGroupStart"); sym(GroupEnd, "ncclGroupEnd");
         sym(GetErrorString, "ncclGetErrorString");
+        if (ok) {
+            CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(so, "ncclCommAbort"));
+            CommGetAsyncError = reinterpret_cast<decltype(CommGetAsyncError)>(dlsym(so, "ncclCommGetAsyncError"));
+        }
         if (!ok) { dlclose(so); so = nullptr; }
         return ok;
     }
@@ -114,6 +122,8 @@ struct Kid {
     hipEvent_t ev[3][2] = {};         // stream time of the exchanges: tau all-gather, saturation hand-off, image exchange + blend
     bool ev_valid[3] = {false, false, false};
     int rc = VP_OK;
+    bool voted = false;               // the failure this rank returned was agreed on by a vote: every local rank left at the same point
+    bool drop_next_send = false;      // VP_MULTI_TEST_DROP_SEND (test hook)
     std::vector<uint64_t> seq_to, seq_from;   // loopback message counters per peer
     std::vector<float> h_xfer;
 };
@@ -151,11 +161,66 @@ struct vp_multi {
     std::mutex mm;
     std::condition_variable mcv;
     std::map<std::tuple<int, int, uint64_t>, Mail> box;
+    // failure handling (round 4).  The reference logs and carries on (VPR.cs:352,790); a fan-out cannot carry on past a rank that left an
+    // exchange, but it must not hang either: whoever notices -- a rank that fails between exchanges, a wait that exceeds the time-out, an
+    // asynchronous RCCL error -- ABORTS the context: the flag wakes every host-side wait (mail boxes, votes), ncclCommAbort ends the
+    // collectives stuck on the devices, every local rank returns VP_ERR_RCCL, and every later call on the context fails fast until it is
+    // destroyed.
+    std::atomic<int> aborted{0};
+    std::mutex am;
+    std::string abort_msg;
+    int timeout_ms = 20000;                   // vp_config.exchange_timeout_ms
 };
 
 namespace {
 
 Kid* local_kid(vp_multi* M, int rank) { return (rank >= M->first_rank && rank < M->first_rank + M->nlocal) ? &M->kids[rank - M->first_rank] : nullptr; }
+
+void multi_abort(vp_multi* M, int rank, const std::string& why)
+{
+    int expected = 0;
+    if (!M->aborted.compare_exchange_strong(expected, 1)) return;           // first reporter wins
+    { std::lock_guard<std::mutex> lk(M->am); M->abort_msg = "rank " + std::to_string(rank) + ": " + why; }
+    fprintf(stderr, "[libvpfx] fan-out aborted by rank %d: %s\n", rank, why.c_str());
+    if (M->use_rccl && rccl().CommAbort)
+        for (Kid& k : M->kids)
+            if (k.comm) { ncclComm_t cm = k.comm; k.comm = nullptr; (void)rccl().CommAbort(cm); }     // ends the kernels of stuck collectives, frees the communicator
+    { std::lock_guard<std::mutex> lk(M->mm); M->mcv.notify_all(); }
+    { std::lock_guard<std::mutex> lk(M->bm); M->bcv.notify_all(); }
+}
+
+int aborted_fail(vp_multi* M, vp_ctx* c)
+{
+    std::lock_guard<std::mutex> lk(M->am);
+    return vp_fail(c, VP_ERR_RCCL, "fan-out context aborted (%s); destroy it and create a new one", M->abort_msg.c_str());
+}
+
+// hipStreamSynchronize with a time-out: an exchange whose peer never arrives (a rank of another process died, a link went down) leaves its
+// kernel spinning on the device for ever.  Polls the stream, the communicator's asynchronous error state and the clock.
+int kid_wait(vp_multi* M, Kid& k, const char* what)
+{
+    vp_ctx* c = k.c;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipStreamQuery(k.stream);
+        if (e == hipSuccess) return M->aborted.load() ? aborted_fail(M, c) : VP_OK;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); multi_abort(M, k.rank, std::string(what) + ": " + hipGetErrorString(e)); return aborted_fail(M, c); }
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (M->aborted.load() && ms > 2000) return aborted_fail(M, c);           // aborted elsewhere and the stream does not drain: give up on it
+        if (M->use_rccl && k.comm && rccl().CommGetAsyncError && (spin & 63) == 63) {
+            ncclResult_t ar = ncclSuccess;
+            if (rccl().CommGetAsyncError(k.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                multi_abort(M, k.rank, std::string(what) + ": asynchronous RCCL error: " + rccl().GetErrorString(ar));
+                return aborted_fail(M, c);
+            }
+        }
+        if (!M->aborted.load() && ms > M->timeout_ms) {
+            multi_abort(M, k.rank, std::string(what) + ": no completion after " + std::to_string(M->timeout_ms) + " ms (a peer left the exchange?)");
+            return aborted_fail(M, c);
+        }
+        if (ms < 2) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
 
 void worker_main(vp_multi* M, int i)
 {
@@ -170,7 +235,9 @@ void worker_main(vp_multi* M, int i)
             seen = M->gen;
             job = M->job;
         }
+        M->kids[i].voted = false;
         const int rc = job(M->kids[i]);
+        if (rc && !M->kids[i].voted) multi_abort(M, M->kids[i].rank, M->kids[i].c->err);      // its peers may be waiting for it in an exchange
         {
             std::lock_guard<std::mutex> lk(M->m);
             M->kids[i].rc = rc;
@@ -183,9 +250,12 @@ void worker_main(vp_multi* M, int i)
 // fan-out context.
 int run_all(vp_multi* M, const std::function<int(Kid&)>& fn)
 {
+    if (M->aborted.load()) return aborted_fail(M, M->parent);
     if (M->nlocal == 1) {
         (void)hipSetDevice(M->kids[0].device);
+        M->kids[0].voted = false;
         M->kids[0].rc = fn(M->kids[0]);
+        if (M->kids[0].rc && !M->kids[0].voted && M->world > 1) multi_abort(M, M->kids[0].rank, M->kids[0].c->err);   // the other processes find out by their time-outs
     } else {
         std::unique_lock<std::mutex> lk(M->m);
         M->job = fn;
@@ -210,7 +280,8 @@ int vote(vp_multi* M, int rc)
         M->b_result = M->b_rc; M->b_rc = 0; M->b_count = 0; ++M->b_gen;
         M->bcv.notify_all();
     } else {
-        M->bcv.wait(lk, [&] { return M->b_gen != g; });
+        M->bcv.wait(lk, [&] { return M->b_gen != g || M->aborted.load(); });
+        if (M->b_gen == g) return rc ? rc : VP_ERR_RCCL;           // aborted while waiting: the vote never completed
     }
     return rc ? rc : M->b_result;
 }
@@ -218,7 +289,7 @@ int vote(vp_multi* M, int rc)
     do {                                                                                                                       \
         const int own_ = (expr);                                                                                               \
         const int all_ = vote(M, own_);                                                                                        \
-        if (all_) return own_ ? own_ : vp_fail(c, all_, "another local rank failed before the collective");                    \
+        if (all_) { k.voted = !M->aborted.load(); return own_ ? own_ : vp_fail(c, all_, "another local rank failed before the collective"); } \
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -258,11 +329,18 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
             void* dst = nullptr;
             {
                 std::unique_lock<std::mutex> lk(M->mm);
-                M->mcv.wait(lk, [&] { auto it = M->box.find(key); return it != M->box.end() && it->second.posted; });
+                const bool ok = M->mcv.wait_for(lk, std::chrono::milliseconds(M->timeout_ms),
+                                                [&] { auto it = M->box.find(key); return (it != M->box.end() && it->second.posted) || M->aborted.load(); });
+                if (!ok || M->aborted.load()) {
+                    lk.unlock();
+                    if (!ok) multi_abort(M, k.rank, "exchange: rank " + std::to_string(o.peer) + " never posted its receive buffer");
+                    return aborted_fail(M, c);
+                }
                 Mail& ml = M->box[key];
                 if (ml.bytes != o.bytes) return vp_fail(c, VP_ERR_STATE, "loopback exchange: size mismatch between ranks %d and %d", k.rank, o.peer);
                 dst = ml.dst;
             }
+            if (k.drop_next_send) { k.drop_next_send = false; continue; }      // TEST HOOK: this rank silently leaves the exchange
             hipEvent_t ev = nullptr;
             VP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             VP_HIP(hipMemcpyAsync(dst, o.ptr, o.bytes, hipMemcpyDefault, k.stream));
@@ -278,7 +356,13 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
         hipEvent_t ev = nullptr;
         {
             std::unique_lock<std::mutex> lk(M->mm);
-            M->mcv.wait(lk, [&] { return M->box[key].done; });
+            const bool ok = M->mcv.wait_for(lk, std::chrono::milliseconds(M->timeout_ms), [&] { return M->box[key].done || M->aborted.load(); });
+            if (!ok || !M->box[key].done) {
+                const int peer = std::get<0>(key);
+                lk.unlock();
+                if (!ok) multi_abort(M, k.rank, "exchange: nothing arrived from rank " + std::to_string(peer) + " within " + std::to_string(M->timeout_ms) + " ms");
+                return aborted_fail(M, c);
+            }
             ev = M->box[key].ev;
             M->box.erase(key);
         }
@@ -318,7 +402,14 @@ void free_kid(Kid& k)
 {
     if (!k.c && !k.stream) return;
     (void)hipSetDevice(k.device);
-    if (k.stream) (void)hipStreamSynchronize(k.stream);
+    if (k.stream) {
+        // bounded: a stream still stuck in an aborted exchange must not hang vp_destroy
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(k.stream) == hipErrorNotReady &&
+               std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() < 5000)
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        (void)hipGetLastError();
+    }
     if (k.comm && rccl().so) (void)rccl().CommDestroy(k.comm);
     void* bufs[] = {k.d_tau_all, k.d_img[0], k.d_img[1], k.d_tmaps, k.d_tout[0], k.d_tout[1], k.d_pieces, k.d_piece_out, k.d_final, k.d_xfer};
     for (void* p : bufs) if (p) (void)hipFree(p);
@@ -364,7 +455,7 @@ int plan_slabs(vp_multi* M, Kid& k)
             rc = all_gather_inplace(M, k, k.d_xfer, stride); if (rc) return rc;
             VP_HIP(hipMemcpyAsync(all.data(), k.d_xfer, all.size() * sizeof(float), hipMemcpyDeviceToHost, k.stream));
         }
-        VP_HIP(hipStreamSynchronize(k.stream));
+        { const int rw = kid_wait(M, k, "slab re-cut (all-gather of the work profile)"); if (rw) return rw; }
         c->binned = c->filled = c->local_done = false;                 // the cursor scratch was reused
         // ms per pair / per sample: measured when a frame has run (sum of kernel ms over ranks / sum of units), else the MI355X C3 figures
         double fill_ms_sum = 0, pairs_sum = 0, rm_ms_sum = 0, samp_sum = 0;
@@ -379,7 +470,12 @@ int plan_slabs(vp_multi* M, Kid& k)
         bool have_rm = false;
         for (int r = 0; r < world; ++r)
             for (int z = 0; z < nz; ++z) { rm_ms[z] += all[(size_t)r * stride + z] * ms_per_sample; have_rm = have_rm || all[(size_t)r * stride + z] > 0.f; }
-        hl_plan_slabs(nz, world, fill_ms.data(), have_rm ? rm_ms.data() : nullptr, M->groups, cuts.data());
+        // every local rank holds the same numbers: ONE of them runs the planner (its exact search is ~world nz^4 / 2 steps), the others take
+        // the published cut after the barrier
+        if (k.index == 0) { hl_plan_slabs(nz, world, fill_ms.data(), have_rm ? rm_ms.data() : nullptr, M->groups, cuts.data()); M->cuts = cuts; }
+        VP_VOTE(VP_OK);
+        cuts = M->cuts;
+        return api_set_slab(c, cuts[k.rank], cuts[k.rank + 1]);
     }
     if (k.index == 0) M->cuts = cuts;
     return api_set_slab(c, cuts[k.rank], cuts[k.rank + 1]);
@@ -401,6 +497,9 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     if (loopback && nlocal != world) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: VP_MULTI_PEER_COPY needs every rank in this process");
     if (cfg->slab_z0 != 0 || cfg->slab_z1 != 0) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: a fan-out context cuts its own slabs (slab_z0 = slab_z1 = 0)");
     if (cfg->rm_groups < 0) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: rm_groups %d", cfg->rm_groups);
+    if (cfg->reserved[2] < 0 || cfg->reserved[2] > 3600000) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: exchange time-out %d ms (vp_config.reserved[2]: 0 = 20 s, at most an hour)", cfg->reserved[2]);
+    if ((cfg->multi_flags & VP_MULTI_TEST_DROP_SEND) && !((cfg->multi_flags & VP_MULTI_TEST_HOOKS) && loopback))
+        return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: VP_MULTI_TEST_DROP_SEND needs VP_MULTI_TEST_HOOKS and VP_MULTI_PEER_COPY");
     int devs[VP_MAX_LOCAL_DEVICES];
     for (int i = 0; i < nlocal; ++i) devs[i] = cfg->num_devices > 0 ? cfg->devices[i] : cfg->device;
     int ndev = 0;
@@ -424,6 +523,7 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     M->world = world; M->nlocal = nlocal; M->first_rank = first; M->flags = cfg->multi_flags;
     M->groups = cfg->rm_groups > 0 ? std::min(cfg->rm_groups, world) : 1;
     M->use_rccl = !loopback;
+    M->timeout_ms = cfg->reserved[2] > 0 ? cfg->reserved[2] : 20000;          // vp_config.reserved[2]: exchange time-out in ms (fan-out contexts)
     M->npix = (size_t)cfg->width * cfg->height;
     M->piece = (M->npix + world - 1) / world;
     M->pixpad = M->piece * world;
@@ -444,8 +544,10 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
         Kid& k = M->kids[i];
         k.index = i; k.rank = first + i; k.device = devs[i];
         k.seq_to.assign(world, 0); k.seq_from.assign(world, 0);
+        k.drop_next_send = (cfg->multi_flags & VP_MULTI_TEST_DROP_SEND) && k.rank == world - 1;
         vp_config one = *cfg;
-        one.num_devices = 0; one.world_size = 0; one.multi_flags = 0; one.first_rank = 0;
+        one.num_devices = 0; one.world_size = 0; one.multi_flags = cfg->multi_flags & VP_MULTI_TEST_HOOKS; one.first_rank = 0;
+        one.reserved[2] = 0;
         one.device = devs[i];
         one.slab_z0 = M->cuts[k.rank]; one.slab_z1 = M->cuts[k.rank + 1];
         int rc = vp_create_single(&one, &k.c);
@@ -650,10 +752,12 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         RmHandoff ho{};
         ho.t_in = n_in ? k.d_tmaps : nullptr; ho.n_in = n_in; ho.plane = M->npix;
         ho.t_out0 = k.d_tout[0]; ho.t_out1 = k.d_tout[1]; ho.zsamples = (M->want_profile && !c->no_zprofile) ? c->d_zsamples : nullptr;   // the profile costs ~3 %: only when a re-cut was asked for
-        hipError_t he = hipMemsetAsync(c->d_zsamples, 0, (size_t)VPFX_ZPROF_COPIES * c->g.Nz * sizeof(unsigned), k.stream);
+        // cleared only on a frame that records into it: a frame between the profiled one and the re-cut (updateInterval > 1) must not wipe it
+        hipError_t he = ho.zsamples ? hipMemsetAsync(c->d_zsamples, 0, (size_t)VPFX_ZPROF_COPIES * c->g.Nz * sizeof(unsigned), k.stream) : hipSuccess;
         r = he == hipSuccess ? launch_raymarch(c, kc, k.d_img[0], k.d_img[1], &ho) : vp_fail(c, VP_ERR_HIP, "hipMemsetAsync failed");
         c->d_scene_depth = keep;
-        if (r) return r;       // (no vote here: with hand-off groups the later groups are still waiting for this rank's maps, step (3))
+        if (r) return r;       // (no vote here: with hand-off groups the later groups are still waiting for this rank's maps, step (3); an unvoted
+                               //  failure ABORTS the context on the way out -- worker_main / run_all -- which wakes them)
         // (3) hand-off out: a phase-A-only slab behind this one is hidden by this slab's phase-A image only (t_out0), every other by both
         ops.clear();
         for (int p = my_pos + 1; p < world; ++p) {
@@ -665,47 +769,37 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         VP_HIP(hipEventRecord(k.ev[2][0], k.stream));
         float* primary = k.d_img[M->cuts[k.rank] <= zb ? 0 : 1];          // first image in blend order: phase A if the slab has one
         float* second = k.d_img[1];                                       // the straddler's phase-B image
-        const size_t pc = M->piece * 4;
+        // The schedule -- who sends which unit to whom, what is copied locally -- is the library's ONE definition of the exchange
+        // (hl_exchange_plan = vp_exchange_plan, also executed over gloo on host buffers by tests/test_fanout_gloo.py); here its sends and
+        // receives become grouped ncclSend / ncclRecv (or peer copies), its all-gather ncclAllGather, its copies stream copies.
+        const size_t unit = (gather_all ? M->pixpad : M->piece) * 4;           // floats per unit: a whole padded image or one screen piece
+        float* const xbuf[5] = {primary, second, k.d_pieces, k.d_piece_out, k.d_final};
         const void* images[VP_MAX_RANKS + 1];
-        if (!gather_all) {
+        auto run_phase = [&](int phase) -> int {
+            vp_xop xo[4 * VP_MAX_RANKS + 8];
+            const int nx = hl_exchange_plan(world, k.rank, strad, gather_all ? 1 : 0, phase, xo, (int)(sizeof xo / sizeof xo[0]));
+            if (nx > (int)(sizeof xo / sizeof xo[0])) return vp_fail(c, VP_ERR_STATE, "exchange plan of %d operations", nx);
             ops.clear();
-            for (int j = 0; j < world; ++j)
-                if (j != k.rank) {
-                    ops.push_back(P2P{false, j, k.d_pieces + (size_t)j * pc, pc * sizeof(float)});
-                    ops.push_back(P2P{true, j, primary + (size_t)j * pc, pc * sizeof(float)});
+            int rr = VP_OK;
+            for (int i = 0; i < nx && !rr; ++i) {
+                const vp_xop& o = xo[i];
+                if (o.kind == VP_XOP_SEND || o.kind == VP_XOP_RECV) {
+                    ops.push_back(P2P{o.kind == VP_XOP_SEND, o.peer, xbuf[o.buf] + (size_t)o.index * unit, unit * sizeof(float)});
+                    continue;
                 }
-            if (strad >= 0) {
-                if (k.rank == strad) { for (int j = 0; j < world; ++j) if (j != k.rank) ops.push_back(P2P{true, j, second + (size_t)j * pc, pc * sizeof(float)}); }
-                else ops.push_back(P2P{false, strad, k.d_pieces + (size_t)world * pc, pc * sizeof(float)});
+                rr = p2p_batch(M, k, ops); ops.clear();                       // a batch ends where the sends / receives end
+                if (rr) break;
+                if (o.kind == VP_XOP_COPY) rr = copy_on_stream(k, xbuf[o.dst_buf] + (size_t)o.dst_index * unit, xbuf[o.buf] + (size_t)o.index * unit, unit * sizeof(float));
+                else if (o.kind == VP_XOP_ALL_GATHER) rr = all_gather_inplace(M, k, xbuf[o.buf], unit);
+                else rr = vp_fail(c, VP_ERR_STATE, "exchange plan: unknown operation %d", o.kind);
             }
-            r = p2p_batch(M, k, ops); if (r) return r;
-            r = copy_on_stream(k, k.d_pieces + (size_t)k.rank * pc, primary + (size_t)k.rank * pc, pc * sizeof(float)); if (r) return r;
-            if (k.rank == strad) { r = copy_on_stream(k, k.d_pieces + (size_t)world * pc, second + (size_t)k.rank * pc, pc * sizeof(float)); if (r) return r; }
-            for (int i = 0; i < n_plan; ++i) images[i] = k.d_pieces + (size_t)(plan_which[i] ? world : plan_rank[i]) * pc;
-            r = launch_blend(c, images, plan_kind, n_plan, k.d_piece_out, M->piece); if (r) return r;
-            // gather the finished pieces on the display rank
-            ops.clear();
-            if (k.rank == 0) { for (int j = 1; j < world; ++j) ops.push_back(P2P{false, j, k.d_final + (size_t)j * pc, pc * sizeof(float)}); }
-            else ops.push_back(P2P{true, 0, k.d_piece_out, pc * sizeof(float)});
-            r = p2p_batch(M, k, ops); if (r) return r;
-            if (k.rank == 0) { r = copy_on_stream(k, k.d_final, k.d_piece_out, pc * sizeof(float)); if (r) return r; }
-        } else {
-            // the north-star form: ONE all-gather of the whole partial images (+ the straddler's second image to the display rank)
-            const size_t ic = M->pixpad * 4;
-            r = copy_on_stream(k, k.d_pieces + (size_t)k.rank * ic, primary, ic * sizeof(float)); if (r) return r;
-            r = all_gather_inplace(M, k, k.d_pieces, ic); if (r) return r;
-            ops.clear();
-            if (strad >= 0 && strad != 0) {
-                if (k.rank == strad) ops.push_back(P2P{true, 0, second, ic * sizeof(float)});
-                else if (k.rank == 0) ops.push_back(P2P{false, strad, k.d_pieces + (size_t)world * ic, ic * sizeof(float)});
-            }
-            r = p2p_batch(M, k, ops); if (r) return r;
-            if (k.rank == 0) {
-                if (strad == 0) { r = copy_on_stream(k, k.d_pieces + (size_t)world * ic, second, ic * sizeof(float)); if (r) return r; }
-                for (int i = 0; i < n_plan; ++i) images[i] = k.d_pieces + (size_t)(plan_which[i] ? world : plan_rank[i]) * ic;
-                r = launch_blend(c, images, plan_kind, n_plan, k.d_final, M->npix); if (r) return r;
-            }
-        }
+            return rr ? rr : p2p_batch(M, k, ops);
+        };
+        r = run_phase(0); if (r) return r;
+        for (int i = 0; i < n_plan; ++i) images[i] = k.d_pieces + (size_t)(plan_which[i] ? world : plan_rank[i]) * unit;
+        if (!gather_all) { r = launch_blend(c, images, plan_kind, n_plan, k.d_piece_out, M->piece); if (r) return r; }
+        else if (k.rank == 0) { r = launch_blend(c, images, plan_kind, n_plan, k.d_final, M->npix); if (r) return r; }
+        r = run_phase(1); if (r) return r;
         VP_HIP(hipEventRecord(k.ev[2][1], k.stream));
         k.ev_valid[2] = true;
         // (5) deliver on the display rank
@@ -713,6 +807,7 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
             if (d_out) VP_HIP(hipMemcpyAsync(d_out, k.d_final, M->npix * 4 * sizeof(float), hipMemcpyDeviceToDevice, k.stream));
             if (host_out) {
                 VP_HIP(hipMemcpyAsync(host_out, k.d_final, M->npix * 4 * sizeof(float), hipMemcpyDeviceToHost, k.stream));
+                { const int rw = kid_wait(M, k, "image exchange"); if (rw) return rw; }
                 return api_stream_sync(c);
             }
         }
@@ -724,7 +819,8 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
 
 int multi_sync(vp_ctx* P)
 {
-    return run_all(P->multi, [&](Kid& k) -> int { return vp_sync(k.c); });
+    vp_multi* M = P->multi;
+    return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_sync"); return rw ? rw : vp_sync(k.c); });
 }
 
 int multi_set_occluders(vp_ctx* P, const vp_obb* boxes, int32_t n)
@@ -836,7 +932,7 @@ VP_EXPORT int vp_get_multi_info(vp_ctx* P, vp_multi_info* out)
     for (Kid& k : M->kids) {
         vp_ctx* c = k.c;
         (void)hipSetDevice(k.device);
-        VP_HIP(hipStreamSynchronize(k.stream));
+        { const int rw = kid_wait(M, k, "vp_get_multi_info"); if (rw) { P->err = c->err; return rw; } }
         unsigned long long s = 0;
         VP_HIP(hipMemcpy(&s, c->d_samples, sizeof s, hipMemcpyDeviceToHost));
         out->samples[k.rank] = (int64_t)s;

@@ -471,6 +471,61 @@ k_tile_rank(const float* __restrict__ cost_in, int nsuper, int* __restrict__ ord
     if (threadIdx.x < 64 && i < nsuper) order[rank[threadIdx.x]] = i;
 }
 
+#if VPFX_AB   // measured and dropped (round 4, profiles/r04_ab/raymarch_wave_shape_and_xcd_affine.txt): one compact screen region per XCD cut the L2->fabric
+              // read volume by only 3-8 % and cost 25-40 % in time (the regions' work is unequal whatever the estimate says); run with VPFX_RM_XCD_AFFINE=1
+// XCD-affine dispatch order (round 4).  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2; with super-tiles dealt out round
+// robin in cost order, the super-tiles that share a brick sit on 3-6 different XCDs and every one of them pulls the brick's lines into its L2
+// again (measured: 2.4 x the sampled bricks' bytes leave the memory side at C3 and at C5, profiles/r04_*).  Here the screen is cut into 8
+// COMPACT regions -- contiguous runs of a Hilbert curve over the super-tile grid (curve[] from the host, fixed per resolution) -- of equal
+// weight, weight = (cost share + count share) / 2: the cost share balances the XCDs' work, the count share bounds a region at
+// nsuper / 4 super-tiles so that the launch can be sized without reading anything back.  Region r's super-tiles go to dispatch positions
+// r, 8 + r, 16 + r, ... most expensive first; the rest of its positions hold -1 (the workgroup exits).  One workgroup; scheduling only.
+__global__ void __launch_bounds__(1024)
+k_tile_regions(const float* __restrict__ cost_in, const int* __restrict__ curve, int nsuper, int cap /* positions per XCD */, int* __restrict__ order)
+{
+    __shared__ float cost[RM_ORDER_MAX];           // along the curve
+    __shared__ float pre[RM_ORDER_MAX];
+    __shared__ float part[1024];
+    __shared__ int start[9];
+    const int t = threadIdx.x;
+    for (int i = t; i < 8 * cap; i += 1024) order[i] = -1;
+    float acc = 0.f;
+    for (int j = t; j < nsuper; j += 1024) { const float c = cost_in[curve[j]]; cost[j] = c; acc += c; }
+    part[t] = acc;
+    __syncthreads();
+    for (int o = 512; o; o >>= 1) { if (t < o) part[t] += part[t + o]; __syncthreads(); }
+    const float total = part[0];
+    __syncthreads();
+    // inclusive prefix of the weights along the curve: each thread owns a contiguous chunk
+    const int per = (nsuper + 1023) / 1024, j0 = min(t * per, nsuper), j1 = min(j0 + per, nsuper);
+    const float wc = total > 0.f ? 0.5f / total : 0.f, wn = (total > 0.f ? 0.5f : 1.0f) / (float)nsuper;
+    float run = 0.f;
+    for (int j = j0; j < j1; ++j) { run += cost[j] * wc + wn; pre[j] = run; }
+    part[t] = run;
+    __syncthreads();
+    if (t == 0) { float a = 0.f; for (int i = 0; i < 1024; ++i) { const float v = part[i]; part[i] = a; a += v; } }
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) pre[j] += part[t];
+    __syncthreads();
+    // region of position j = floor(8 x exclusive prefix): monotone along the curve, so region r is the run [start[r], start[r + 1])
+    auto region = [&](int j) { return min(7, (int)(8.0f * (j ? pre[j - 1] : 0.f))); };
+    if (t < 9) {
+        int lo = 0, hi = nsuper;                                   // first j with region(j) >= t
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (region(mid) >= t) hi = mid; else lo = mid + 1; }
+        start[t] = t == 8 ? nsuper : lo;
+    }
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) {
+        const int r = region(j), a = start[r], b = start[r + 1];
+        const float c = cost[j];
+        int rk = 0;
+        for (int i = a; i < b; ++i) rk += (cost[i] > c || (cost[i] == c && i < j)) ? 1 : 0;
+        if (rk < cap) order[8 * rk + r] = curve[j];
+    }
+}
+
+#endif  // VPFX_AB (k_tile_regions)
+
 // PARTIAL = false: the reference's single render target.  PARTIAL = true: OVER-phase and UNDER-phase MVs of the
 // owned slab composite into two separate images (multi-GPU partial images).
 // FLAGS = false compiles the vp_raymarch_params.flags paths (UNORM8 emulation, debug views) out of the hot loop.
@@ -492,7 +547,7 @@ __global__ void __launch_bounds__(64, (PARTIAL && FLAGS) ? VPFX_RM_WAVES_PARTIAL
 k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restrict__ bricks, const float4* __restrict__ mvtrans,
            const int* __restrict__ rank, const float* __restrict__ scene_depth, float4* __restrict__ img_over, float4* __restrict__ img_under,
            unsigned long long* __restrict__ samples, int* __restrict__ brick_hit, const int* __restrict__ tile_order, int early_out,
-           RmHandoff ho, const float4* __restrict__ cellinfo, const uint32_t* __restrict__ occmask)
+           RmHandoff ho, const float4* __restrict__ cellinfo, const uint32_t* __restrict__ occmask, int order_len)
 {
     const int lane = threadIdx.x;
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
@@ -500,15 +555,20 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     // rendered entirely by one XCD, so a brick is pulled into ~2-4 L2s instead of all eight, while consecutive super-tiles
     // of the dispatch order (cost-sorted, see k_tile_cost) alternate XCDs (load balance).
     constexpr int LX = VPFX_RM_LX, LY = VPFX_RM_LY, WPS = 4 << (LX + LY);            // waves per super-tile
-    const int tgx = (k.W + 15) >> 4, tgy = (k.H + 15) >> 4;
-    const int sgx = (tgx + (1 << LX) - 1) >> LX, sgy = (tgy + (1 << LY) - 1) >> LY;
+    constexpr int SW = 16 << LX, SH = 16 << LY;                                     // super-tile size in pixels
+    const int sgx = (k.W + SW - 1) / SW, sgy = (k.H + SH - 1) / SH;
     const int q = (int)(blockIdx.x >> 3);
-    const int within = q % WPS, wave = within & 3, j = within >> 2;                // tile j of the super-tile, wave of the tile
+    const int within = q % WPS;                                                    // wave of the super-tile
     const int slot = (q / WPS) * 8 + (int)(blockIdx.x & 7u);                       // position in the dispatch order
-    if (slot >= sgx * sgy) return;
+    if (slot >= (tile_order ? order_len : sgx * sgy)) return;
     const int sti = tile_order ? tile_order[slot] : slot;                          // super-tile index
-    const int ttx = ((sti % sgx) << LX) + (j & ((1 << LX) - 1)), tty = ((sti / sgx) << LY) + (j >> LX);
-    if (ttx >= tgx || tty >= tgy) return;
+    if (sti < 0) return;                                                           // (padding of an XCD's share of the dispatch order)
+    // The wave's pixel block: 2^wave_lx pixels along the lane-fastest screen axis x 64 / 2^wave_lx along the other (8 x 8, 16 x 4 or 32 x 2;
+    // RmConsts.wave_lx, hl_build_rm_consts).  A brick row is a run of 128-byte lines along grid x, and at one lattice index the rows of a
+    // pixel block sit on different (y, z) brick rows, so the lines a wave-sample touches ~ (rows of the block) x (lines per row): an
+    // elongated block touches fewer, at the price of a less compact ray bundle.
+    const int bwl = k.lane_transpose ? 6 - k.wave_lx : k.wave_lx, bhl = 6 - bwl;    // log2 of the block's width and height in pixels
+    const int wx = within & ((SW >> bwl) - 1), wy = within >> (LX + 4 - bwl);
 #if VPFX_RM_OCC_LDS
     // The cell walk crosses about two empty cells for every occupied one, and learning that a cell is empty used to cost a dependent global
     // load (31 % of the wave time sat in the walk, scripts/raymarch_phase_profile.py).  The grid's occupancy is one bit per cell: 4 KB at
@@ -525,9 +585,9 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     // lanes row-major in the tile: the L1 serves a wave-load one lane quad per cycle when the quad's addresses share a 128-B line
     // (scripts/probes/l1_gather_probe.hip), and four pixels in a screen row share a brick row more often than a 2 x 2 px quad does
     // (Z-order lanes: 1.62 ms against 1.46).
-    const int lx = k.lane_transpose ? lane >> 3 : lane & 7, ly = k.lane_transpose ? lane & 7 : lane >> 3;   // (hl_build_rm_consts)
-    const int col = ttx * 16 + (wave & 1) * 8 + lx;
-    const int row = tty * 16 + (wave >> 1) * 8 + ly;
+    const int lx = k.lane_transpose ? lane >> bhl : lane & ((1 << bwl) - 1), ly = k.lane_transpose ? lane & ((1 << bhl) - 1) : lane >> bwl;   // (hl_build_rm_consts)
+    const int col = (sti % sgx) * SW + (wx << bwl) + lx;
+    const int row = (sti / sgx) * SH + (wy << bhl) + ly;
     if (col >= k.W || row >= k.H) return;
 
 #if VPFX_RM_PROBE == 9
@@ -758,6 +818,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
 #endif
 }
 
+#if VPFX_AB   // measured-and-dropped A/B variant (2.2-3.9 x slower): only in `make EXTRA=-DVPFX_AB=1` builds, run with VPFX_RM_FLAT=1
 // ---------------------------------------------------------------------------------------------------------------------------------
 // k_raymarch_flat: the same ray-march with a WAVE-COHERENT traversal (whole-grid or slab contexts; border >= 1, no flag paths).
 // k_raymarch nests "for every metavoxel the ray meets { for every sample in it }": the 64 rays of a wave enter, cross and leave a metavoxel
@@ -1083,6 +1144,8 @@ k_raymarch_flat(RmConsts k, const int* __restrict__ brick_index, const uint2* __
     if (nsamp) atomicAdd(samples, (unsigned long long)nsamp);
 }
 
+#endif  // VPFX_AB (k_raymarch_flat)
+
 // _OrderIndex of every occupied metavoxel = its position in the submission order of RenderMetavoxels (mvCount, VPR.cs:650-706):
 // phase A (zz <= zBoundary) zz ascending, cells far -> near (rank descending); phase B zz ascending, cells near -> far.  Brick
 // slots are z-major, so the MVs of slice zz occupy consecutive slots and "occupied MVs in front of slice zz" = own slot minus the
@@ -1174,27 +1237,36 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
 {
     const int nsuper = rm_num_super_tiles(k.W, k.H);
     const int* order = nullptr;
+    int order_len = nsuper;
 #ifndef VPFX_RM_NO_ORDER
     if (nsuper <= RM_ORDER_MAX) {
-        float* cost = reinterpret_cast<float*>(c->d_tile_order + nsuper + 8);
+        float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));
         hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, rm_super_tiles_x(k.W), cost);
-        hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
+#if VPFX_AB
+        if (c->rm_xcd_affine && c->d_tile_curve) {
+            const int cap = rm_order_cap(nsuper);
+            hipLaunchKernelGGL(k_tile_regions, dim3(1), dim3(1024), 0, c->stream, cost, c->d_tile_curve, nsuper, cap, c->d_tile_order);
+            order_len = 8 * cap;
+        } else
+#endif
+            hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
         order = c->d_tile_order;
     }
 #endif
-    const dim3 grid(((nsuper + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
+    const dim3 grid(((order_len + 7) / 8) * 8 * (4 << (VPFX_RM_LX + VPFX_RM_LY))), block(64);
     hipLaunchKernelGGL((k_raymarch<NV, PARTIAL, WRAP, FLAGS, GREY>), grid, block, 0, c->stream, k, c->d_brick_index, c->d_bricks, c->d_mvtrans,
                        c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out, ho,
-                       (const float4*)c->d_cellinfo, (const uint32_t*)c->d_occmask);
+                       (const float4*)c->d_cellinfo, (const uint32_t*)c->d_occmask, order_len);
 }
 
+#if VPFX_AB
 template <int NV, bool PARTIAL, bool GREY>
 void launch_rm_flat(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
 {
     const int nsuper = rm_num_super_tiles(k.W, k.H);
     const int* order = nullptr;
     if (nsuper <= RM_ORDER_MAX) {
-        float* cost = reinterpret_cast<float*>(c->d_tile_order + nsuper + 8);
+        float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));
         hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, rm_super_tiles_x(k.W), cost);
         hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
         order = c->d_tile_order;
@@ -1204,15 +1276,19 @@ void launch_rm_flat(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under,
                        c->d_rank, c->d_scene_depth, (float4*)d_over, (float4*)d_under, c->d_samples, c->d_brick_hit, order, early_out, ho);
 }
 
+#endif
+
 template <int NV>
 void launch_rm_nv(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
 {
     const bool wrap = c->g.b < 1;          // only a border-less brick can filter across its faces (wrap = Repeat)
+#if VPFX_AB
     if (c->rm_flat && !wrap && !k.flags) { // the wave-coherent traversal (border >= 1, no debug views / UNORM8 emulation)
         if (c->bricks_grey) { if (d_under) launch_rm_flat<NV, true, true>(c, k, d_over, d_under, early_out, ho); else launch_rm_flat<NV, false, true>(c, k, d_over, d_under, early_out, ho); }
         else { if (d_under) launch_rm_flat<NV, true, false>(c, k, d_over, d_under, early_out, ho); else launch_rm_flat<NV, false, false>(c, k, d_over, d_under, early_out, ho); }
         return;
     }
+#endif
     const int sel = (d_under ? 4 : 0) | (wrap ? 2 : 0) | (k.flags ? 1 : 0);
     if (c->bricks_grey) {                  // (luminance, density) bricks: only ever filled with border >= 1
         switch (sel & 5) {
@@ -1261,6 +1337,7 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
     if (!c->d_cellinfo) VP_HIP(hipMalloc((void**)&c->d_cellinfo, c->n3 * sizeof(float4)));
     if (k.occ_lds && !c->d_occmask) VP_HIP(hipMalloc((void**)&c->d_occmask, VPFX_RM_OCC_WORDS * sizeof(uint32_t)));
 #endif
+    c->brick_hit_n = nocc;
     // one launch prepares the frame: translations, per-cell records, occupancy rows, cleared hit flags and sample counter (k_rm_prepare)
     hipLaunchKernelGGL(k_rm_prepare, dim3((unsigned)((c->n3 + 255) / 256)), dim3(256), 0, c->stream, k, c->d_brick_index, c->d_mvPos, (int)c->n3,
                        c->d_mvtrans, c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr, c->d_brick_hit, c->d_samples);

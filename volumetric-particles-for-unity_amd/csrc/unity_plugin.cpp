@@ -9,6 +9,7 @@
 // The entry points follow the shape of Unity's public plugin API (IUnityInterface.h: UnityPluginLoad / UnityPluginUnload exported by
 // name, a `void (*)(int eventId)` rendering event); Unity's own headers are not needed and not used: IUnityInterfaces* is kept as an
 // opaque pointer.  Nothing here is Unity-specific beyond that calling convention, so the tests drive it from a second host thread.
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 
@@ -23,8 +24,10 @@ struct Slot {
     float* h_out = nullptr;
     int status = VP_ERR_STATE;
     unsigned long long events = 0;
+    bool running = false;         // an event of this slot is executing (vp_unity_clear_slot waits for it)
 };
 std::mutex g_m;
+std::condition_variable g_cv;
 Slot g_slots[VP_UNITY_MAX_SLOTS];
 void* g_unity_interfaces = nullptr;
 bool g_loaded = false;
@@ -37,8 +40,9 @@ void on_render_event(int slot)
     float* h_out;
     {
         std::lock_guard<std::mutex> lk(g_m);
-        if (!g_slots[slot].have_frame) { g_slots[slot].status = VP_ERR_STATE; ++g_slots[slot].events; return; }
+        if (!g_slots[slot].have_frame) { g_slots[slot].status = VP_ERR_STATE; ++g_slots[slot].events; return; }     // (also: an event that arrives after vp_unity_clear_slot)
         f = g_slots[slot].frame; d_out = g_slots[slot].d_out; h_out = g_slots[slot].h_out;
+        g_slots[slot].running = true;
     }
     int rc = VP_OK;
     vp_ctx* c = f.ctx;
@@ -56,6 +60,8 @@ void on_render_event(int slot)
     std::lock_guard<std::mutex> lk(g_m);
     g_slots[slot].status = rc;
     ++g_slots[slot].events;
+    g_slots[slot].running = false;
+    g_cv.notify_all();
 }
 
 }  // namespace
@@ -112,3 +118,18 @@ VP_EXPORT int vp_unity_last_status(int32_t slot, uint64_t* events_run)
     if (events_run) *events_run = g_slots[slot].events;
     return g_slots[slot].status;
 }
+
+// Detach a slot from its context and buffers: waits for an event of the slot that is executing right now, then forgets the frame
+// description and the outputs -- an event Unity delivers later finds nothing and is a no-op (status VP_ERR_STATE).  The host calls this
+// BEFORE it frees the arrays the description points to and before vp_destroy: the render thread may run an issued event at any later time.
+VP_EXPORT int vp_unity_clear_slot(int32_t slot)
+{
+    if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS) return VP_ERR_BAD_ARG;
+    std::unique_lock<std::mutex> lk(g_m);
+    g_cv.wait(lk, [&] { return !g_slots[slot].running; });
+    const unsigned long long ev = g_slots[slot].events;
+    g_slots[slot] = Slot{};
+    g_slots[slot].events = ev;                 // the counter keeps counting: hosts compare it with the number of events they issued
+    return VP_OK;
+}
+

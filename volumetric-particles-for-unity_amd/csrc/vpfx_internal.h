@@ -58,6 +58,7 @@ struct FillConsts {
 struct RmConsts {
     int W, H, Nx, Ny, Nz, nv, z0, z1;
     int zB, steps, soft, partial;
+    int wave_lx;                  // log2 of the ray-march wave's pixel-block extent along the lane-fastest screen axis: 3 = 8 x 8, 4 = 16 x 4, 5 = 32 x 2 (k_raymarch)
     int flags, num_covered, lane_transpose, occ_lds;  // (occ_lds: the grid's occupancy bitmask fits k_raymarch's LDS copy, launch_raymarch)  VP_RM_* bits of vp_raymarch_params.flags; _NumMetavoxelsCovered (VPR.cs:755); lanes run down screen columns
     float aspect, neg_inv_tan, zMin, s;
     float mvStep, inv_mvStep, nearc, farc;
@@ -107,6 +108,8 @@ struct vp_ctx {
     vp_config cfg{};
     vp_multi* multi = nullptr;    // non-null: a fan-out context (its slabs live in child contexts); every entry point forwards
     bool test_chain_timeout = false;
+    bool rm_xcd_affine = false;   // dispatch order of k_raymarch: compact screen region per XCD (k_tile_regions) instead of round robin in cost order
+    int* d_tile_curve = nullptr;  // [super-tiles] Hilbert order of the super-tile grid (host-built at vp_create)
     bool rm_flat = false;         // VPFX_RM_FLAT=1 at vp_create: the wave-coherent ray-march traversal (k_raymarch_flat) -- A/B switch
     bool no_zprofile = false;     // VPFX_NO_ZPROFILE=1 in the environment at vp_create: measurement switch, slab ray-march without the per-slice sample profile
     int device = 0;
@@ -183,7 +186,7 @@ struct vp_ctx {
     uint32_t* d_occmask = nullptr; // [Nz][Ny] one bit per cell (Nx <= 32): occupied metavoxels, copied into LDS by k_raymarch for the cell walk
     float4* d_cellinfo = nullptr; // [N^3] (translation, brick slot | -1) per cell: VPFX_RM_CELLINFO A/B variant of the cell walk
     int* d_rank = nullptr;        // [Ny*Nx]
-    int* d_tile_order = nullptr;  // [2 x (super-tiles + 8)] dispatch order of k_raymarch (most expensive first), then the float cost estimates
+    int* d_tile_order = nullptr;  // [rm_order_ints + super-tiles] dispatch order of k_raymarch (most expensive first), then the float cost estimates
     int* h_rank = nullptr;
     float* d_image = nullptr;     // [H][W][4]
     float* d_scene_depth = nullptr;
@@ -191,6 +194,7 @@ struct vp_ctx {
     unsigned* d_zsamples = nullptr; // [VPFX_ZPROF_COPIES][Nz] samples executed per light-axis slice by the last slab ray-march (RmHandoff::zsamples)
     int* d_brick_hit = nullptr;   // [brick_hit_cap] set to 1 by the ray-march when a brick contributes a sample
     size_t brick_hit_cap = 0;
+    int brick_hit_n = 0;          // metavoxels of the last ray-march (entries of d_brick_hit that frame used)
     long long last_samples = 0;
 
     hipEvent_t ev[4][2]{};        // start/stop of the dominant kernel per stage: 0 bin, 1 fill (fused or local), 2 raymarch, 3 fill_finish
@@ -217,6 +221,10 @@ void   hl_build_psys(vp_ctx* c, const float m[16]);
 void   hl_build_fill_consts(vp_ctx* c, const vp_fill_params* p);
 int    hl_z_boundary(const vp_ctx* c, const vp_camera* cam);             //           VPR.cs:642-648
 // ray-march screen decomposition: wave = 8x8 px, tile = 16x16 px (4 waves), super-tile = (16 << LX) x (16 << LY) px
+// A/B builds (make EXTRA=-DVPFX_AB=1) carry the measured-and-dropped variants and their environment switches; the shipped library does not
+#ifndef VPFX_AB
+#define VPFX_AB 0
+#endif
 #ifndef VPFX_RM_LX
 #define VPFX_RM_LX 2
 #endif
@@ -226,10 +234,15 @@ int    hl_z_boundary(const vp_ctx* c, const vp_camera* cam);             //     
 inline int rm_super_tiles_x(int W) { return (((W + 15) / 16) + (1 << VPFX_RM_LX) - 1) >> VPFX_RM_LX; }
 inline int rm_super_tiles_y(int H) { return (((H + 15) / 16) + (1 << VPFX_RM_LY) - 1) >> VPFX_RM_LY; }
 inline int rm_num_super_tiles(int W, int H) { return rm_super_tiles_x(W) * rm_super_tiles_y(H); }
+// dispatch-order buffer of the ray-march (d_tile_order): [8 x cap] positions (XCD-affine order: region r owns r, 8 + r, ...; cap = the most
+// super-tiles a region can hold, k_tile_regions), then the float cost estimates [nsuper]
+inline int rm_order_cap(int nsuper) { return nsuper / 4 + 2; }
+inline int rm_order_ints(int nsuper) { return 8 * rm_order_cap(nsuper) + 8; }
 void   hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank);  //           VPR.cs:613-632
 // slab cut + compositing order of the slabs (host only)
 void   hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms, int rm_groups, int* cuts /* [world + 1] */);
 int    hl_blend_plan(int world, const int* cuts, int zb, int* chain, int* plan_rank, int* plan_which, int* plan_kind, int* straddler);
+int    hl_exchange_plan(int world, int rank, int strad, int all_gather, int phase, vp_xop* ops, int cap);     // message schedule of the image exchange (vp_exchange_plan)
 void   hl_chain_groups(int world, int rm_groups, int* group_of_pos /* [world]: group of chain position p */);
 void   hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k);
 

@@ -325,6 +325,16 @@ def blend_plan(bounds, z_boundary: int):
     return list(chain[:world]), [(pr[i], pw[i], pk[i]) for i in range(n.value)], (None if strad.value < 0 else strad.value)
 
 
+def exchange_plan(world: int, rank: int, straddler, all_gather: bool, phase: int):
+    """The library's message schedule of the image exchange for one rank (host only): a list of abi.vp_xop, in execution order."""
+    ops = (abi.vp_xop * (4 * world + 8))()
+    n = C.c_int32(0)
+    rc = lib().vp_exchange_plan(int(world), int(rank), -1 if straddler is None else int(straddler), 1 if all_gather else 0, int(phase), ops, len(ops), C.byref(n))
+    if rc:
+        raise VpfxError("vp_exchange_plan", rc, lib().vp_last_error(None).decode())
+    return [ops[i] for i in range(n.value)]
+
+
 def _copy_cfg(cfg):
     out = abi.vp_config()
     C.memmove(C.byref(out), C.byref(cfg), C.sizeof(abi.vp_config))
