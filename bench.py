@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--no-grey", action="store_true", help="A/B: keep RGBA16F bricks although the ambient colour is grey")
     ap.add_argument("--displacement-scale", type=float, default=None,
                     help="override the scene's _DisplacementScale (default 0.7, scene:9016); 1.0 = the slider's maximum (smoothstep jump at net displacement 0)")
+    ap.add_argument("--event-stride", type=int, default=0, help="read the stages' HIP-event kernel times every n-th timed step (0 = steps // 64, at least 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--share-gpu", action="store_true",
@@ -297,12 +298,16 @@ def main():
     k_fill, k_rm, k_bin, k_fin = [], [], [], []
     frame_no[0] = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    # HIP-event durations of the dominant kernels are READ inside the timed region, on the stream they were launched on (N > 1: the slowest
+    # local rank) -- but reading one waits for that launch (hipEventSynchronize), which stops the host from running ahead of the GPU: three
+    # waits per frame are a third of a 0.3 ms frame.  So they are read on every stride-th step (>= 64 samples of every stage per run).
+    stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // 64)
+    for i in range(args.steps):
         step()
-        # HIP-event durations of the dominant kernels, recorded on the stream they were launched on (N > 1: the slowest local rank)
-        k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))
-        if N > 1:
-            k_fin.append(eng.last_kernel_ms(3))
+        if i % stride == stride - 1 or i == args.steps - 1:
+            k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))
+            if N > 1:
+                k_fin.append(eng.last_kernel_ms(3))
     barrier()
     dt = time.perf_counter() - t0
     st = eng.stats()
@@ -390,7 +395,7 @@ def main():
             "metric": baseline_metric(),
             "value": (voxels / update_interval + samples) / (dt / args.steps) / 1e6,        # (DEMO: the fill runs every 2nd frame)
             "unit": "M(voxels+samples)/s",
-            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "kernel_time_samples_per_stage": len(k_fill),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 compute / f16 voxel storage", "data": "synthetic",
             "config": {"workload": f"{args.config}: {sc.N[0]}x{sc.N[1]}x{sc.N[2]} metavoxels x {nv}^3 voxels, "

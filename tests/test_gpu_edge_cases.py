@@ -81,6 +81,26 @@ def test_fade_and_radians_and_moved_particle_system():
     check(sc)
 
 
+@pytest.mark.parametrize("width,height,rolled", [(96, 64, False), (61, 47, False), (96, 64, True), (640, 400, False)])
+def test_both_wave_pixel_block_shapes_render_the_oracle_frame(width, height, rolled):
+    """k_raymarch's wave covers 8 x 8 pixels while a pixel is about a texel or less and 16 x 4 (4 x 16 when the lanes run down the
+    columns: rolled views) once the ray lattice is sparser than the texels (hl_build_rm_consts: pixel > 1.25 texels at the grid centre).
+    Scheduling only -- both must give the oracle's frame with the oracle's samples, at image sizes that are not multiples of either block."""
+    sc = S.make_scene("C1", cubemap="r8")
+    sc.width, sc.height = width, height
+    if rolled:
+        pos = np.asarray(sc.cam_pos, dtype=np.float64)
+        f = -pos / np.linalg.norm(pos)
+        right = np.cross((0.0, 1.0, 0.0), f); right /= np.linalg.norm(right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = np.cross(f, right) * -1.0, right, -f, pos      # camera rolled by 90 degrees about its axis
+        sc.cam_to_world, sc.world_to_cam = c2w, np.linalg.inv(c2w)
+    dist = float(np.linalg.norm(np.asarray(sc.cam_pos) - np.asarray(sc.grid_center)))
+    texels_per_pixel = (2.0 * dist * np.tan(np.radians(60.0) / 2) / height) / (sc.mv_scale / (sc.nv - 2 * sc.border))
+    assert (texels_per_pixel > 1.25) == (height < 100)          # the first three cases take the 16 x 4 block, the last the 8 x 8 one
+    check(sc, exact=False)
+
+
 @pytest.mark.parametrize("dims", [(5, 16, 200, 80, 60), (3, 32, 60, 64, 64)])
 def test_odd_grids(dims):
     check(S.make_scene("odd", dims=dims))
