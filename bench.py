@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--displacement-scale", type=float, default=None,
                     help="override the scene's _DisplacementScale (default 0.7, scene:9016); 1.0 = the slider's maximum (smoothstep jump at net displacement 0)")
     ap.add_argument("--event-stride", type=int, default=0, help="read the stages' HIP-event kernel times every n-th timed step (0 = steps // 64, at least 1)")
+    ap.add_argument("--no-formula-count", action="store_true", help="skip the one untimed ray-march without early-out that counts SURVEY 8(d)'s formula samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--share-gpu", action="store_true",
@@ -283,11 +284,13 @@ def main():
     # SURVEY 8(d) defines Msamples/s on the FORMULA count (sum over pixels and metavoxels of max(0, tExit - tEntry + 1)): one untimed ray-march
     # with the saturation early-out off (VP_RM_NO_EARLY_OUT) executes exactly those samples on the resident bricks.  The timed frames keep the
     # early-out (same image), so both counts and both rates are reported.
-    rp_all = sc.raymarch_params()
-    rp_all.flags |= abi.VP_RM_NO_EARLY_OUT
-    eng.raymarch_device(cam, rp_all, image.data_ptr())
-    eng.sync()
-    samples_formula_local = eng.stats()["samples"]
+    samples_formula_local = 0
+    if not args.no_formula_count:      # (profiling runs leave it out: the extra launch has the same kernel name and would sit in rocprofv3's per-kernel averages)
+        rp_all = sc.raymarch_params()
+        rp_all.flags |= abi.VP_RM_NO_EARLY_OUT
+        eng.raymarch_device(cam, rp_all, image.data_ptr())
+        eng.sync()
+        samples_formula_local = eng.stats()["samples"]
     # N > 1: re-cut the slabs twice from the measured work (pairs per slice, samples executed per slice, kernel times), then keep the cut:
     # vp_rebalance makes the NEXT ray-march record its per-slice samples and the bin after that re-cut, hence the extra step at the end
     for i in range(max(args.warmup - 1, 3 if N > 1 else 0)):
@@ -412,7 +415,7 @@ def main():
                        "slabs": [[a, b] for a, b in zip(info["slab_cuts"], info["slab_cuts"][1:])] if N > 1 else None,
                        "occupied_mv": int(occupied), "pairs": int(pairs), "voxels_per_step": int(voxels),
                        "samples_per_step": int(samples),
-                       "samples_executed": int(samples), "samples_formula": int(samples_formula),
+                       "samples_executed": int(samples), "samples_formula": int(samples_formula) if samples_formula else None,
                        "work_unit": ("voxels + executed samples of the 1-GPU job (fixed for every N)" if (N == 1 or ref_units is not None)
                                      else "voxels + samples executed on all ranks (1-GPU reference job not run: see reference_frame_skipped)"),
                        "samples_executed_all_ranks": int(executed[1]),
@@ -421,8 +424,8 @@ def main():
             # and for the whole frame (everything incl. the exchanges)
             "fill_mvoxels_per_s": voxels / fill_t / 1e6,
             "raymarch_msamples_per_s": samples / (smax[2] * 1e-3) / 1e6,                    # executed samples (the saturation early-out skips the hidden ones)
-            "raymarch_msamples_per_s_formula": samples_formula / (smax[2] * 1e-3) / 1e6,    # SURVEY 8(d)'s count (what the CPU leg executes) over the same kernel time
-            "value_formula_units": (voxels / update_interval + samples_formula) / (dt / args.steps) / 1e6,   # the frame's work in the units of the CPU leg
+            "raymarch_msamples_per_s_formula": (samples_formula / (smax[2] * 1e-3) / 1e6) if samples_formula else None,    # SURVEY 8(d)'s count (what the CPU leg executes) over the same kernel time
+            "value_formula_units": ((voxels / update_interval + samples_formula) / (dt / args.steps) / 1e6) if samples_formula else None,   # the frame's work in the units of the CPU leg
             "frame_mvoxels_per_s": voxels / (dt / args.steps) / 1e6,
             "frame_msamples_per_s": samples / (dt / args.steps) / 1e6,
             "fill_frac_of_hbm_roofline": roofs["fill"]["frac"],
@@ -442,7 +445,7 @@ def main():
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_threads, demo_boxes)   # (one frame WITH bin + fill; DEMO refills every 2nd frame)
             # equal units on both sides: the CPU port executes every formula sample, so the GPU frame is credited with the same work
-            out["speedup_vs_cpu"] = out["value_formula_units"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu"] = (out["value_formula_units"] or out["value"]) / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_note"] = ("(voxels + FORMULA samples) per second, GPU frame / CPU port; in executed samples the GPU figure is `value` "
                                           f"({out['value'] / out['cpu_baseline']['value']:.0f}x), which credits the early-out with nothing")
         print(json.dumps(out))

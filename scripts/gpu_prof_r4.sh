@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${PROF_DIR:-prof_r4}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline ${BENCH_ARGS}"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-formula-count ${BENCH_ARGS}"
 timeout -k 5 ${KT_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $CMD > $OUT/kt_bench.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \

@@ -62,10 +62,11 @@ def mix(body):
         if not op.startswith("v_") or op.startswith("v_readlane") or op.startswith("v_readfirstlane") and False: continue
         c, r = classify(op)
         w = 8.0 ** depth[i]
-        a = agg.setdefault(c, {"w": 0.0, "wr": 0.0, "ops": {}})
+        a = agg.setdefault(c, {"w": 0.0, "wr": 0.0, "wi": 0.0, "ops": {}})
         a["w"] += w; a["wr"] += w * r
+        a["wi"] += w * (2.0 if r < 3.2 else 8.0 if 6.0 < r < 12.0 else 4.0)      # the pipe's nominal rate: SIMD-32 full rate 2, half rate 4, transcendental 8 cycles per wave64
         a["ops"][op] = a["ops"].get(op, 0) + 1
-    return {c: {"avg_issue_cycles": a["wr"] / a["w"], "static_ops": dict(sorted(a["ops"].items(), key=lambda kv: -kv[1])[:12])} for c, a in agg.items()}
+    return {c: {"avg_issue_cycles": a["wr"] / a["w"], "avg_nominal_cycles": a["wi"] / a["w"], "static_ops": dict(sorted(a["ops"].items(), key=lambda kv: -kv[1])[:12])} for c, a in agg.items()}
 import hashlib
 def kernel_sources_sha():
     h = hashlib.sha256()
