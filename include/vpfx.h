@@ -32,8 +32,10 @@
 extern "C" {
 #endif
 
-#define VPFX_ABI_VERSION 3   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
-                                3: vp_config device list (multi-GPU fan-out inside the library, RCCL), VP_ERR_RCCL, Unity plugin entry points */
+#define VPFX_ABI_VERSION 4   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
+                                3: vp_config device list (multi-GPU fan-out inside the library, RCCL), VP_ERR_RCCL, Unity plugin entry points
+                                4: same struct layouts; new: vp_config.reserved[2] = exchange time-out of a fan-out context (abort instead of hang),
+                                   VP_MULTI_TEST_HOOKS / VP_MULTI_TEST_DROP_SEND, VP_RM_NO_EARLY_OUT, vp_exchange_plan, vp_unity_clear_slot */
 
 typedef enum vp_status {
     VP_OK = 0,

@@ -34,7 +34,7 @@ VP_BRICKS_RGBA16F, VP_BRICKS_GREY_ZPAIR = 0, 1
 VP_CUBEMAP_F32 = 0
 VP_CUBEMAP_R8 = 1
 
-VPFX_ABI_VERSION = 3
+VPFX_ABI_VERSION = 4
 
 STATUS_NAMES = {
     0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
