@@ -1,0 +1,12 @@
+# round 4, final evidence on the final sources (one GPU call): -m gpu suite, rocprofv3 passes (C3, C5), bench lines, view sweep, fuzz sweep
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r4_final; mkdir -p $OUT
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $OUT/pytest_gpu.txt
+PROF_DIR=prof_r4_C3 STEPS=10 bash scripts/gpu_prof_r4.sh > $OUT/prof_C3_tail.txt 2>&1
+PROF_DIR=prof_r4_C5 BENCH_ARGS="--config C5" STEPS=3 bash scripts/gpu_prof_r4.sh > $OUT/prof_C5_tail.txt 2>&1
+for c in C3 C5; do cp gpurun_out/prof_r4_$c/traffic.json profiles/traffic_${c}_r8.json; cp gpurun_out/prof_r4_$c/limiters.json profiles/limiters_${c}_r8.json; done   # (so that the bench lines below carry them)
+timeout 900 python bench.py --steps 300 > $OUT/bench_C3.json 2> $OUT/bench_C3.err
+timeout 600 python bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_C5.json 2> $OUT/bench_C5.err
+for cfg in DEMO C1 C2; do timeout 600 python bench.py --config $cfg --steps 400 --warmup 5 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; done
+timeout 600 python scripts/view_sweep.py C3 2>&1 | grep -v amdgpu.ids | tee $OUT/view_sweep_C3.txt
+timeout 1500 python scripts/fuzz_parity.py ${FUZZ:-3000} 960000 2>&1 | tail -1 | tee $OUT/fuzz.log

@@ -10,9 +10,9 @@ places the voxels (x, y at texel centres, z at the texel's near face: Q4) and co
                                                  slab shapes: the wave-uniform slice RANGE of the tile, as k_fill_lds walks it)
     (tile, particle) set-ups                     per-(wave, particle) work outside the loop (quadratic solve, DPP reduction, record load)
 The 8x8x1 row must reproduce the kernel's own counter (1.573 G covered voxels in 40.3 M covered wave-slices = 39.0 of 64 lanes).
-usage: fill_tile_shapes.py [C3] [metavoxels to sample = 400]"""
+usage: tests/tools/fill_tile_shapes.py [C3] [metavoxels to sample = 400]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 load_package()
