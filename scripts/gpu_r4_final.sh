@@ -10,3 +10,6 @@ timeout 600 python bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline >
 for cfg in DEMO C1 C2; do timeout 600 python bench.py --config $cfg --steps 400 --warmup 5 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; done
 timeout 600 python scripts/view_sweep.py C3 2>&1 | grep -v amdgpu.ids | tee $OUT/view_sweep_C3.txt
 timeout 1500 python scripts/fuzz_parity.py ${FUZZ:-3000} 960000 2>&1 | tail -1 | tee $OUT/fuzz.log
+# where a frame of the reference's own scene goes: per-kernel trace of the DEMO bench
+export TMPDIR=/tmp; rm -rf $OUT/demo_kt; (cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/demo_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --config DEMO --steps 200 --warmup 5 --no-cpu-baseline --no-formula-count > /dev/null 2>&1)
+python scripts/rocprof_summary.py $OUT/demo_kt/kt_results.db 2>/dev/null | head -30 | cut -c1-110 | tee $OUT/demo_kernel_trace.txt; rm -rf $OUT/demo_kt

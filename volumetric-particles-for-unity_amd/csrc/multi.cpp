@@ -841,6 +841,7 @@ vp_ctx* multi_owner_of_slice(vp_ctx* P, int zz)
 int multi_get_stats(vp_ctx* P, vp_stats* st)
 {
     vp_multi* M = P->multi;
+    if (M->aborted.load()) return aborted_fail(M, P);          // (these touch the slab contexts' streams directly: never on an aborted fan-out)
     memset(st, 0, sizeof *st);
     for (Kid& k : M->kids) {
         vp_stats s;
@@ -858,6 +859,7 @@ int multi_get_stats(vp_ctx* P, vp_stats* st)
 int multi_last_kernel_ms(vp_ctx* P, int stage, float* ms)
 {
     vp_multi* M = P->multi;
+    if (M->aborted.load()) return aborted_fail(M, P);          // (these touch the slab contexts' streams directly: never on an aborted fan-out)
     float worst = 0.f;
     for (Kid& k : M->kids) {
         float v = 0.f;
@@ -873,6 +875,7 @@ int multi_last_kernel_ms(vp_ctx* P, int stage, float* ms)
 int multi_read_bincounts(vp_ctx* P, int32_t* counts)
 {
     vp_multi* M = P->multi;
+    if (M->aborted.load()) return aborted_fail(M, P);          // (these touch the slab contexts' streams directly: never on an aborted fan-out)
     const vp_config& cfg = P->cfg;
     const size_t nxy = (size_t)cfg.num_mv[0] * cfg.num_mv[1], n3 = nxy * cfg.num_mv[2];
     memset(counts, 0, n3 * sizeof(int32_t));
@@ -889,6 +892,7 @@ int multi_read_bincounts(vp_ctx* P, int32_t* counts)
 int multi_read_lightmap(vp_ctx* P, float* out)
 {
     vp_multi* M = P->multi;
+    if (M->aborted.load()) return aborted_fail(M, P);          // (these touch the slab contexts' streams directly: never on an aborted fan-out)
     Kid* last = local_kid(M, M->world - 1);                     // lightPropogationTex after the whole grid = the last slab's light map
     if (!last) return vp_fail(P, VP_ERR_STATE, "vp_read_lightmap: the last slab (rank %d) is not on this process", M->world - 1);
     const int rc = vp_read_lightmap(last->c, out);
