@@ -3,6 +3,7 @@
   slab   what the kernel does: within a light-axis slab the wave marches "the r-th occupied metavoxel of every lane" together and all lanes
          meet again at the slab's end (a lane with one metavoxel in the slab idles while another marches its second);
   mv     a traversal that streams across slabs: round r = the r-th occupied metavoxel of every lane's whole ray (no meeting at slab ends);
+  lattice  all lanes step the ray lattice index together, front to back, each sampling where its ray is inside an occupied metavoxel;
   ray    lanes only idle once their whole ray is done (scripts/lane_bound.py's bound; what the 2.2x slower state-machine kernel of round 3 aimed at).
 Every round costs the longest lane's samples (two per loop iteration).  Rays, lattice and per-metavoxel sample ranges follow RM.shader:188-240 as
 the kernels do; occupancy = the oracle's bins (test infrastructure: this tool lives with the tests).  Early-out is ignored (formula samples).
@@ -38,7 +39,7 @@ step = 1.73205 / steps                                     # lattice step in met
 fov = np.radians(60.0)
 rng = np.random.default_rng(3)
 tiles = [(int(rng.integers(0, W // 8)), int(rng.integers(0, H // 8))) for _ in range(ntiles)]
-tot = dict(useful=0, slab=0, mv=0, ray=0)
+tot = dict(useful=0, slab=0, mv=0, ray=0, lattice=0)
 for tx, ty in tiles:
     seqs = []
     for ly in range(8):
@@ -70,18 +71,22 @@ for tx, ty in tiles:
                     if t_in > t_out: continue
                     te, tx_ = max(int(np.ceil(t_in / step)), tcam), int(np.floor(t_out / step))
                     n = max(0, tx_ - te + 1)
-                    if n > 0: seq.append((zz, n))
+                    if n > 0: seq.append((zz, n, te, tx_))
             seqs.append(seq)
-    useful = sum(n for sq in seqs for _, n in sq)
+    useful = sum(q[1] for sq in seqs for q in sq)
     it = lambda n: 2 * ((n + 1) // 2)                         # samples are taken two per loop iteration
     slab_cost = 0
     for zz in range(N[2]):
-        per = [[n for z, n in sq if z == zz] for sq in seqs]
+        per = [[q[1] for q in sq if q[0] == zz] for sq in seqs]
         for r in range(max(len(p) for p in per)):
             slab_cost += max(it(p[r]) if r < len(p) else 0 for p in per)
     mv_cost = sum(max(it(sq[r][1]) if r < len(sq) else 0 for sq in seqs) for r in range(max((len(sq) for sq in seqs), default=0)))
-    ray_cost = max((sum(n for _, n in sq) for sq in seqs), default=0)
-    tot["useful"] += useful; tot["slab"] += 64 * slab_cost; tot["mv"] += 64 * mv_cost; tot["ray"] += 64 * ray_cost
+    ray_cost = max((sum(q[1] for q in sq) for sq in seqs), default=0)
+    ks = set()
+    for sq in seqs:
+        for q in sq: ks.update(range(q[2] // 2, q[3] // 2 + 1))          # lattice indices, two per loop iteration
+    lat_cost = 2 * len(ks)
+    tot["useful"] += useful; tot["slab"] += 64 * slab_cost; tot["mv"] += 64 * mv_cost; tot["ray"] += 64 * ray_cost; tot["lattice"] += 64 * lat_cost
 print(f"{name}: {ntiles} wave tiles, {tot['useful'] / ntiles / 64:.0f} formula samples per ray")
-for k in ("slab", "mv", "ray"):
-    print(f"  sync per {k:4s}: lane use of the sample loops {tot['useful'] / max(tot[k], 1):.3f}")
+for k in ("slab", "mv", "lattice", "ray"):
+    print(f"  sync per {k:7s}: lane use of the sample loops {tot['useful'] / max(tot[k], 1):.3f}")
