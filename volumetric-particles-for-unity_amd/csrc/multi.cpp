@@ -218,7 +218,7 @@ int kid_wait(vp_multi* M, Kid& k, const char* what)
             multi_abort(M, k.rank, std::string(what) + ": no completion after " + std::to_string(M->timeout_ms) + " ms (a peer left the exchange?)");
             return aborted_fail(M, c);
         }
-        if (ms < 2) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (ms < 10) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));     // a frame's wait is a few ms: no sleep granularity on it
     }
 }
 
