@@ -155,7 +155,8 @@ def test_library_slab_planner_is_valid_and_optimal():
 
 
 def test_library_blend_plan_matches_the_python_pipeline_and_orders_front_to_back():
-    from vpfx_amd import engine as E, parallel as PAR
+    from vpfx_amd import engine as E
+    import slab_reference as PAR
     rng = np.random.default_rng(11)
     for trial in range(200):
         nz = int(rng.integers(2, 20)); world = int(rng.integers(1, min(nz, 8) + 1))
