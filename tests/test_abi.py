@@ -31,6 +31,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.vp_abi_version() == abi.VPFX_ABI_VERSION == 4
 
 
+def test_header_constants_match_the_mirror():
+    """Every numeric #define of the header that the ctypes mirror also names has the same value (flags, enums of the exchange plan, ABI)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(VP[A-Z_0-9]*)\s+(0x[0-9a-fA-F]+|-?\d+)\b", src)}
+    checked = 0
+    for name, value in defs.items():
+        if hasattr(abi, name):
+            assert getattr(abi, name) == value, name
+            checked += 1
+    assert checked >= 25, checked
+    for name in ("VP_RM_NO_EARLY_OUT", "VP_MULTI_TEST_HOOKS", "VP_MULTI_TEST_DROP_SEND", "VP_XOP_ALL_GATHER", "VP_XBUF_FINAL", "VPFX_ABI_VERSION"):
+        assert name in defs and hasattr(abi, name), name
+
+
 def test_struct_layouts_match_header():
     code = r'''
 #include <stdio.h>

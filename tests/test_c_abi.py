@@ -13,7 +13,7 @@ from vpfx_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "volumetric-particles-for-unity_amd")
-STRUCTS = ["vp_config", "vp_particle_layout", "vp_fill_params", "vp_camera", "vp_raymarch_params", "vp_obb", "vp_stats", "vp_multi_info"]
+STRUCTS = ["vp_config", "vp_particle_layout", "vp_fill_params", "vp_camera", "vp_raymarch_params", "vp_obb", "vp_stats", "vp_multi_info", "vp_xop"]
 
 
 def _cc(args, **kw):
