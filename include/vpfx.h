@@ -35,7 +35,7 @@ extern "C" {
 #define VPFX_ABI_VERSION 4   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
                                 3: vp_config device list (multi-GPU fan-out inside the library, RCCL), VP_ERR_RCCL, Unity plugin entry points
                                 4: same struct layouts; new: vp_config.reserved[2] = exchange time-out of a fan-out context (abort instead of hang),
-                                   VP_MULTI_TEST_HOOKS / VP_MULTI_TEST_DROP_SEND, VP_RM_NO_EARLY_OUT, vp_exchange_plan, vp_unity_clear_slot */
+                                   VP_MULTI_TEST_HOOKS / VP_MULTI_TEST_DROP_SEND, VP_RM_NO_EARLY_OUT, vp_exchange_plan, vp_unity_clear_slot, vp_unity_register_output_fd */
 
 typedef enum vp_status {
     VP_OK = 0,
@@ -443,6 +443,12 @@ int  vp_unity_set_frame_desc(int32_t slot, const vp_unity_frame* frame);
 /* Where the event writes particlesRT ([H][W][4] f32 premultiplied): a HIP device pointer (written by the ray-march itself) and / or a host
  * buffer (read back after it).  At least one must be non-NULL when the event runs. */
 int  vp_unity_register_output(int32_t slot, void* d_rgba_out, float* h_rgba_out);
+/* Texture interop, the native half: `fd` = the memory behind the render texture's linear RGBA32F buffer, exported by the graphics API as a POSIX
+ * file descriptor (Vulkan: VkExportMemoryAllocateInfo + vkGetMemoryFdKHR; opaque fd / dma-buf), `bytes` its allocation size.  Imports it with HIP's
+ * external-memory API on the context's display device, maps W*H*16 bytes at `offset` and registers the mapping as the slot's DEVICE output (replacing
+ * d_rgba_out of vp_unity_register_output; the host output is kept): the ray-march writes the shared memory directly -- what VPR.cs:204-210 does on the
+ * GPU, without the PCIe round trip.  HIP owns the fd after a successful import.  vp_unity_clear_slot / UnityPluginUnload drop the import. */
+int  vp_unity_register_output_fd(int32_t slot, vp_ctx* ctx, int32_t fd, uint64_t bytes, uint64_t offset);
 /* Status of the most recent event of the slot (Unity's callback returns void) and how many events have run. */
 int  vp_unity_last_status(int32_t slot, uint64_t* events_run);
 /* Detach the slot: waits for an event of the slot that is executing right now, then forgets its frame description and outputs, so that an

@@ -3,6 +3,7 @@ description per slot, and the render-event callback that Unity would invoke on i
 second host thread.  The frame it produces must be the one the direct calls produce (VPR.cs:181-220: set-up, bin + fill every updateInterval
 frames, ray-march every frame)."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -10,6 +11,8 @@ import pytest
 import torch
 
 from vpfx_amd import abi, engine as E, scene as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +95,50 @@ def test_render_event_runs_the_frame_on_another_thread(fanout):
     L.UnityPluginUnload()
     assert L.vp_unity_last_status(slot, C.byref(ev)) == abi.VP_ERR_STATE and ev.value == 0          # unloading forgets every slot
     eng.close(); direct.close()
+
+
+def test_render_target_shared_through_an_exported_fd(tmp_path):
+    """Texture interop, the native half (vp_unity_register_output_fd): the memory behind the host's render texture arrives as a POSIX fd exported by
+    the graphics API; the library imports it through HIP's external-memory API and the ray-march writes it directly (VPR.cs:204-210 blits particlesRT
+    on the GPU; without this the frame crosses PCIe).  No Vulkan on the box: the producer is HIP's own virtual-memory API exporting a dma-buf fd
+    (tests/tools/extmem_producer.cpp) -- the import path is the one a Vulkan export takes.  The producer's own view of the memory must hold the frame."""
+    import subprocess
+    so = str(tmp_path / "libextmem_producer.so")
+    subprocess.run(["g++", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "tools", "extmem_producer.cpp"),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-o", so], check=True)
+    P = C.CDLL(so)
+    P.producer_create.argtypes = [C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    P.producer_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L = E.lib()
+    L.vp_unity_render_event_func.restype = C.CFUNCTYPE(None, C.c_int)
+    L.vp_unity_register_output_fd.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64]
+    sc = S.make_scene("C1", cubemap="r8")
+    direct = E.Engine(sc.config())
+    direct.set_frame(sc.light_to_world, sc.grid_center)
+    direct.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    direct.fill(sc.fill_params())
+    ref = direct.raymarch(sc.camera(), sc.raymarch_params())
+    eng = E.Engine(sc.config())
+    need, offset = sc.width * sc.height * 16, 1 << 16
+    fd, view, size = C.c_int(-1), C.c_void_p(), C.c_size_t(0)
+    assert P.producer_create(need + offset, C.byref(fd), C.byref(view), C.byref(size)) == 0
+    L.UnityPluginLoad(None)
+    slot = 2
+    assert L.vp_unity_register_output_fd(slot, eng.h, fd.value, size.value, size.value) == abi.VP_ERR_BAD_ARG      # no room behind that offset
+    assert L.vp_unity_register_output_fd(slot, eng.h, -1, size.value, 0) == abi.VP_ERR_BAD_ARG
+    assert L.vp_unity_register_output_fd(slot, eng.h, fd.value, size.value, offset) == 0, L.vp_last_error(eng.h)
+    particles = np.ascontiguousarray(sc.particles)
+    frame = _desc(sc, eng, abi.VP_UNITY_SET_FRAME | abi.VP_UNITY_BIN_AND_FILL, particles)
+    assert L.vp_unity_set_frame_desc(slot, C.byref(frame)) == 0
+    _issue_plugin_event(L.vp_unity_render_event_func(), slot)
+    assert L.vp_unity_last_status(slot, None) == 0, L.vp_last_error(eng.h)
+    eng.sync()
+    got = np.zeros((sc.height, sc.width, 4), dtype=np.float32)
+    assert P.producer_read(view, offset, got.ctypes.data_as(C.c_void_p), got.nbytes) == 0
+    assert np.array_equal(got, ref)                                  # the "texture" holds the frame, written by the ray-march itself
+    assert L.vp_unity_clear_slot(slot) == 0                          # drops the import; a late event is a no-op
+    _issue_plugin_event(L.vp_unity_render_event_func(), slot)
+    assert L.vp_unity_last_status(slot, None) == abi.VP_ERR_STATE
+    L.UnityPluginUnload()
+    eng.close(); direct.close()
+

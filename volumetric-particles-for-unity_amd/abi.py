@@ -208,7 +208,7 @@ EXPORTED_SYMBOLS = [
     "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",
     "vp_raymarch_partial_handoff_device", "vp_read_zsamples",
     "vp_get_multi_info", "vp_rebalance", "vp_rccl_unique_id", "vp_plan_slabs", "vp_blend_plan", "vp_exchange_plan",
-    "vp_unity_render_event_func", "vp_unity_set_frame_desc", "vp_unity_register_output", "vp_unity_last_status", "vp_unity_clear_slot",
+    "vp_unity_render_event_func", "vp_unity_set_frame_desc", "vp_unity_register_output", "vp_unity_register_output_fd", "vp_unity_last_status", "vp_unity_clear_slot",
 ]
 class vp_xop(C.Structure):
     """One operation of the image exchange's message schedule (vp_exchange_plan)."""

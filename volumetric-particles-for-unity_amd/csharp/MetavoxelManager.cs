@@ -121,6 +121,7 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_unity_register_output(int slot, IntPtr dRgbaOut, IntPtr hRgbaOut);
         [DllImport(LIB)] static extern int vp_unity_last_status(int slot, out ulong eventsRun);
         [DllImport(LIB)] static extern int vp_unity_clear_slot(int slot);
+        [DllImport(LIB)] static extern int vp_unity_register_output_fd(int slot, IntPtr ctx, int fd, ulong bytes, ulong offset);   // texture interop: the exported render-texture memory
 
         IntPtr ctx = IntPtr.Zero;
         ParticleSystem.Particle[] parts;

@@ -25,12 +25,24 @@ struct Slot {
     int status = VP_ERR_STATE;
     unsigned long long events = 0;
     bool running = false;         // an event of this slot is executing (vp_unity_clear_slot waits for it)
+    hipExternalMemory_t ext = nullptr;   // vp_unity_register_output_fd: the imported allocation d_out points into
+    int ext_device = 0;
 };
 std::mutex g_m;
 std::condition_variable g_cv;
 Slot g_slots[VP_UNITY_MAX_SLOTS];
 void* g_unity_interfaces = nullptr;
 bool g_loaded = false;
+
+// the mapping of an imported allocation dies with the import: drop both (the slot's d_out pointed into it)
+void release_external(Slot& s)
+{
+    if (!s.ext) return;
+    (void)hipSetDevice(s.ext_device);
+    (void)hipDeviceSynchronize();                     // nothing of ours may still be writing the shared memory
+    (void)hipDestroyExternalMemory(s.ext);
+    s.ext = nullptr; s.d_out = nullptr;
+}
 
 void on_render_event(int slot)
 {
@@ -86,7 +98,7 @@ VP_EXPORT void UnityPluginLoad(void* unity_interfaces)
 VP_EXPORT void UnityPluginUnload(void)
 {
     std::lock_guard<std::mutex> lk(g_m);
-    for (Slot& s : g_slots) s = Slot{};
+    for (Slot& s : g_slots) { release_external(s); s = Slot{}; }
     g_unity_interfaces = nullptr;
     g_loaded = false;
 }
@@ -111,6 +123,43 @@ VP_EXPORT int vp_unity_register_output(int32_t slot, void* d_rgba_out, float* h_
     return VP_OK;
 }
 
+// Texture interop, the native half (VPR.cs:204-210 blits particlesRT on the GPU -- here the frame crossed PCIe).  The graphics API
+// exports the memory behind the texture's linear RGBA32F buffer as a POSIX fd (Vulkan: VkExportMemoryAllocateInfo + vkGetMemoryFdKHR, opaque fd or
+// dma-buf); this imports it through HIP's external-memory API on the context's (display) device, maps `W H 16` bytes at `offset`, and registers the
+// mapping as the slot's DEVICE output: the ray-march then writes the shared memory itself, no copy.  The fd belongs to HIP after a successful import
+// (do not close it).  vp_unity_clear_slot / UnityPluginUnload drop the import.  Ordering against the graphics queue is the host's business (a
+// timeline semaphore imported with hipImportExternalSemaphore, waited / signalled on the stream given to vp_set_stream: INTEGRATION.md).
+// Tested with a dma-buf fd exported by HIP's own virtual-memory API standing in for the graphics API (tests/test_gpu_unity_plugin.py).
+VP_EXPORT int vp_unity_register_output_fd(int32_t slot, vp_ctx* ctx, int32_t fd, uint64_t bytes, uint64_t offset)
+{
+    if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS || !ctx) return VP_ERR_BAD_ARG;
+    vp_ctx* c = ctx->multi ? multi_owner_of_slice(ctx, -1) : ctx;
+    if (!c) return vp_fail(ctx, VP_ERR_STATE, "vp_unity_register_output_fd: the display rank is not on this process");
+    const uint64_t need = (uint64_t)c->cfg.width * c->cfg.height * 4 * sizeof(float);
+    if (fd < 0 || offset > bytes || bytes - offset < need)
+        return vp_fail(ctx, VP_ERR_BAD_ARG, "vp_unity_register_output_fd: %llu bytes at offset %llu of a %llu-byte allocation (particlesRT needs %llu)",
+                       (unsigned long long)(bytes - (offset > bytes ? bytes : offset)), (unsigned long long)offset, (unsigned long long)bytes, (unsigned long long)need);
+    if (hipSetDevice(c->device) != hipSuccess) return vp_fail(ctx, VP_ERR_HIP, "hipSetDevice failed");
+    hipExternalMemoryHandleDesc d;
+    memset(&d, 0, sizeof d);
+    d.type = hipExternalMemoryHandleTypeOpaqueFd; d.handle.fd = fd; d.size = bytes;
+    hipExternalMemory_t ext = nullptr;
+    hipError_t e = hipImportExternalMemory(&ext, &d);
+    if (e != hipSuccess) { (void)hipGetLastError(); return vp_fail(ctx, VP_ERR_HIP, "hipImportExternalMemory failed: %s", hipGetErrorString(e)); }
+    hipExternalMemoryBufferDesc b;
+    memset(&b, 0, sizeof b);
+    b.offset = offset; b.size = need;
+    void* dptr = nullptr;
+    e = hipExternalMemoryGetMappedBuffer(&dptr, ext, &b);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipDestroyExternalMemory(ext); return vp_fail(ctx, VP_ERR_HIP, "hipExternalMemoryGetMappedBuffer failed: %s", hipGetErrorString(e)); }
+    std::unique_lock<std::mutex> lk(g_m);
+    g_cv.wait(lk, [&] { return !g_slots[slot].running; });
+    release_external(g_slots[slot]);
+    g_slots[slot].ext = ext; g_slots[slot].ext_device = c->device;
+    g_slots[slot].d_out = dptr;
+    return VP_OK;
+}
+
 VP_EXPORT int vp_unity_last_status(int32_t slot, uint64_t* events_run)
 {
     if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS) return VP_ERR_BAD_ARG;
@@ -128,6 +177,7 @@ VP_EXPORT int vp_unity_clear_slot(int32_t slot)
     std::unique_lock<std::mutex> lk(g_m);
     g_cv.wait(lk, [&] { return !g_slots[slot].running; });
     const unsigned long long ev = g_slots[slot].events;
+    release_external(g_slots[slot]);
     g_slots[slot] = Slot{};
     g_slots[slot].events = ev;                 // the counter keeps counting: hosts compare it with the number of events they issued
     return VP_OK;
