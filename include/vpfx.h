@@ -65,7 +65,7 @@ typedef struct vp_config {
     int32_t reserved[3];      /* 0.  (Measurement switches: [0] = 1 keeps an R8 cube map out of LDS,
                                  [1] = 1 keeps RGBA16F bricks when the ambient colour is grey.  [2]: single-device context: must be
                                  0; fan-out context: time-out in ms of every inter-rank exchange and of every wait for one
-                                 (0 = 20 000; <= 3 600 000) -- when it expires the context ABORTS: ncclCommAbort on every local
+                                 (0 = 120 000: RCCL sets its peer connections up lazily inside the first exchanges, which can take many seconds on 8 GPUs; <= 3 600 000) -- when it expires the context ABORTS: ncclCommAbort on every local
                                  communicator, every local rank returns VP_ERR_RCCL, every later call fails fast until vp_destroy.
                                  Any other value is refused with VP_ERR_BAD_ARG.)                    */
     /* ---- ABI 3: multi-GPU fan-out INSIDE the library ("device list", "multi-GPU fan-out is internal").

@@ -3,7 +3,7 @@
 # communicator).  Ordered so that the first failure is the most informative one: RCCL chatter on, one log per rank, ONE collective type
 # first (--exchange all_gather: ncclAllGather + one send/recv pair), then the default exchange (grouped ncclSend/ncclRecv all-to-all), first
 # one process for all GPUs (ncclCommInitAll from the library's worker threads), then one process per GPU (ncclCommInitRank, torchrun).
-# Every exchange is bounded by the library's time-out (vp_config.reserved[2], default 20 s): a rank that leaves an exchange makes every rank
+# Every exchange is bounded by the library's time-out (vp_config.reserved[2], default 120 s): a rank that leaves an exchange makes every rank
 # return VP_ERR_RCCL (and the process exit non-zero) instead of hanging the node; each step also runs under `timeout`.
 # usage: scripts/first_8gpu_run.sh [N=8] [steps=20]       logs: gpurun_out/first_8gpu/
 N=${1:-8}; STEPS=${2:-20}

@@ -169,7 +169,7 @@ struct vp_multi {
     std::atomic<int> aborted{0};
     std::mutex am;
     std::string abort_msg;
-    int timeout_ms = 20000;                   // vp_config.exchange_timeout_ms
+    int timeout_ms = 120000;                  // vp_config.exchange_timeout_ms
 };
 
 namespace {
@@ -523,7 +523,7 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     M->world = world; M->nlocal = nlocal; M->first_rank = first; M->flags = cfg->multi_flags;
     M->groups = cfg->rm_groups > 0 ? std::min(cfg->rm_groups, world) : 1;
     M->use_rccl = !loopback;
-    M->timeout_ms = cfg->reserved[2] > 0 ? cfg->reserved[2] : 20000;          // vp_config.reserved[2]: exchange time-out in ms (fan-out contexts)
+    M->timeout_ms = cfg->reserved[2] > 0 ? cfg->reserved[2] : 120000;   // (generous: the first exchanges also pay for RCCL's lazy peer-connection set-up)         // vp_config.reserved[2]: exchange time-out in ms (fan-out contexts)
     M->npix = (size_t)cfg->width * cfg->height;
     M->piece = (M->npix + world - 1) / world;
     M->pixpad = M->piece * world;
