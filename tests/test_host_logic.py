@@ -172,3 +172,21 @@ def test_library_blend_plan_matches_the_python_pipeline_and_orders_front_to_back
         a_only = [r for r in range(world) if bounds[r][1] - 1 <= zb]
         b_only = [r for r in range(world) if bounds[r][0] > zb]
         assert chain == ([strad] if strad is not None else []) + sorted(a_only, reverse=True) + sorted(b_only)
+
+
+def test_planner_stays_cheap_on_deep_grids():
+    """the exact two-maxima search is ~world nz^4 / 2 steps (over half a billion at nz = 128); above 64 slices the planner keeps to its
+    min-max candidates.  A 128-slice grid must still get a valid, balanced cut in well under a second."""
+    import time
+    import numpy as np
+    from vpfx_amd import engine as E
+    rng = np.random.default_rng(5)
+    nz, world = 128, 8
+    fill = np.exp(-((np.arange(nz) - 64.0) / 30.0) ** 2) + 0.01 * rng.random(nz)
+    rm = np.exp(-np.arange(nz) / 20.0)
+    t0 = time.perf_counter()
+    b = E.plan_slabs(nz, world, fill_ms=fill, rm_ms=rm)
+    assert time.perf_counter() - t0 < 2.0
+    assert b[0][0] == 0 and b[-1][1] == nz and all(z1 > z0 for z0, z1 in b) and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+    worst = max(fill[z0:z1].sum() for z0, z1 in b)
+    assert worst <= 2.0 * fill.sum() / world                      # no slab carries more than twice the mean fill work

@@ -497,7 +497,7 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     if (loopback && nlocal != world) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: VP_MULTI_PEER_COPY needs every rank in this process");
     if (cfg->slab_z0 != 0 || cfg->slab_z1 != 0) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: a fan-out context cuts its own slabs (slab_z0 = slab_z1 = 0)");
     if (cfg->rm_groups < 0) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: rm_groups %d", cfg->rm_groups);
-    if (cfg->reserved[2] < 0 || cfg->reserved[2] > 3600000) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: exchange time-out %d ms (vp_config.reserved[2]: 0 = 20 s, at most an hour)", cfg->reserved[2]);
+    if (cfg->reserved[2] < 0 || cfg->reserved[2] > 3600000) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: exchange time-out %d ms (vp_config.reserved[2]: 0 = 120 s, at most an hour)", cfg->reserved[2]);
     if ((cfg->multi_flags & VP_MULTI_TEST_DROP_SEND) && !((cfg->multi_flags & VP_MULTI_TEST_HOOKS) && loopback))
         return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: VP_MULTI_TEST_DROP_SEND needs VP_MULTI_TEST_HOOKS and VP_MULTI_PEER_COPY");
     int devs[VP_MAX_LOCAL_DEVICES];
