@@ -72,6 +72,9 @@ extern "C" __attribute__((visibility("default"))) int vpfx_rm_probe_read(unsigne
 #define VPFX_RM_PROF_PASS
 #define VPFX_RM_PROF_DUMMY
 #endif
+#ifndef VPFX_RM_SPI
+#define VPFX_RM_SPI 4          // lattice samples per loop iteration on grey bricks (see march_mv); 2 = rounds 2-3 (A/B, with VPFX_RM_WAVES_GREY=5)
+#endif
 #ifndef VPFX_RM_OCC_LDS
 #define VPFX_RM_OCC_LDS 1       // occupancy bitmask of the grid in LDS for the cell walk (k_raymarch); 0 = A/B
 #endif
@@ -290,6 +293,35 @@ __device__ __forceinline__ bool march_mv(const RmConsts& k, const RayCtx& R, con
     // in flight per wave -- 1.49 vs 1.48 ms: loads in flight per wave are not what limits the kernel.)
     // (Grey bricks, measured: four samples per iteration -- 8 loads in flight -- 1.02 ms at 4 waves/SIMD against 1.09 for two, but the
     // two-sample loop fits 5 waves/SIMD: 1.00 ms.)
+#if VPFX_RM_SPI == 4
+    // Four lattice samples per iteration on grey bricks (eight loads in flight), the two-sample loop below takes the remainder.  Launches with
+    // few waves per SIMD (small screens: the reference's own 1024 x 768 demo, config 1) run the loop at the pace of one memory round trip per
+    // iteration: 4 samples at 4 waves/SIMD against 2 at 5 -- DEMO 0.118 -> 0.103 ms, C1 0.139 -> 0.122, C2 0.460 -> 0.450, C3 0.940 = 0.940
+    // (profiles/r04_ab/raymarch_four_samples_per_iteration.txt).  Same arithmetic per sample in the same order: bit-identical images.
+    if constexpr (GREY && !FLAGS) {          // (the debug-view / UNORM8 kernels keep the two-sample loop: their extra state would spill)
+        for (; si - 3 >= tSoft; si -= 4) {
+            const Addr a0 = address(fsi), a1 = address(fsi - 1.0f), a2 = address(fsi - 2.0f), a3 = address(fsi - 3.0f);
+            fsi -= 4.0f;
+            u32x4 u0, u1, v0, v1, w0, w1, x0, x1;
+            issue_load16<0>(u0, a0.p); issue_load16<NV * 8>(u1, a0.p);
+            issue_load16<0>(v0, a1.p); issue_load16<NV * 8>(v1, a1.p);
+            issue_load16<0>(w0, a2.p); issue_load16<NV * 8>(w1, a2.p);
+            issue_load16<0>(x0, a3.p); issue_load16<NV * 8>(x1, a3.p);
+            wait_pair<6>(u0, u1);
+            const F4 c0 = filter_grey(QuadG{u0[0], u0[2], u1[0], u1[2], u0[1], u0[3], u1[1], u1[3]}, a0);
+            blend(c0, c0.w);
+            wait_pair<4>(v0, v1);
+            const F4 c1 = filter_grey(QuadG{v0[0], v0[2], v1[0], v1[2], v0[1], v0[3], v1[1], v1[3]}, a1);
+            blend(c1, c1.w);
+            wait_pair<2>(w0, w1);
+            const F4 c2 = filter_grey(QuadG{w0[0], w0[2], w1[0], w1[2], w0[1], w0[3], w1[1], w1[3]}, a2);
+            blend(c2, c2.w);
+            wait_pair<0>(x0, x1);
+            const F4 c3 = filter_grey(QuadG{x0[0], x0[2], x1[0], x1[2], x0[1], x0[3], x1[1], x1[3]}, a3);
+            blend(c3, c3.w);
+        }
+    }
+#endif
     for (; si - 1 >= tSoft; si -= 2) {
         const Addr a0 = address(fsi), a1 = address(fsi - 1.0f);
         fsi -= 2.0f;
@@ -537,7 +569,7 @@ k_tile_regions(const float* __restrict__ cost_in, const int* __restrict__ curve,
 #define VPFX_RM_WAVES_PARTIAL 3   // partial images + flag paths (debug views of a slab): the one combination that needs > 128 VGPRs
 #endif
 #ifndef VPFX_RM_WAVES_GREY
-#define VPFX_RM_WAVES_GREY 5      // the grey-brick kernels without flag paths need 95 VGPRs (whole grid and slab): 5 waves/SIMD without scratch (1.00 vs 1.09 ms at C3)
+#define VPFX_RM_WAVES_GREY 4      // round 4: four samples per iteration (VPFX_RM_SPI) at 4 waves/SIMD; rounds 2-3: two samples, 95 VGPRs, 5 waves/SIMD (1.00 vs 1.09 ms at C3 then)
 #endif
 // (RmHandoff: vpfx_internal.h)
 #define VPFX_RM_HANDOFF_CUTOFF 2.98023224e-8f          // 2^-25
