@@ -1,5 +1,5 @@
 """Where a k_fill_lds wave spends its time: reads the in-kernel phase timer of a PROFILING build of the library
-(scripts/build_ab.sh prof "-DVPFX_PROBE=9"; the timer brackets the phases with s_memtime and sums wave-cycles over all waves).
+(scripts/build_ab.sh prof "-DVPFX_AB=1 -DVPFX_PROBE=9"; the timer brackets the phases with s_memtime and sums wave-cycles over all waves).
 usage (GPU box): python scripts/fill_phase_profile.py _ab/libvpfx_prof.so [C3] [r8]"""
 import sys, os, ctypes, shutil
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,11 @@ try:
     from vpfx_amd import abi, engine as E, scene as S
     name = sys.argv[2] if len(sys.argv) > 2 else "C3"
     cube = sys.argv[3] if len(sys.argv) > 3 else "r8"
-    sc = S.make_scene(name, cubemap=cube)
+    if name == "DEMO":
+        sc, _, boxes = S.make_demo_scene()
+        sc.cubemap = S.make_cubemap_r8() if cube == "r8" else sc.cubemap
+    else:
+        sc = S.make_scene(name, cubemap=cube)
     lib = E.lib()
     lib.vpfx_probe_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     e = E.Engine(sc.config())
