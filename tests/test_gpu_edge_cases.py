@@ -199,6 +199,29 @@ def test_refill_and_rebin_are_idempotent():
     np.testing.assert_array_equal(imgs[0], imgs[2])
 
 
+@pytest.mark.parametrize("N", [4, 12])
+def test_a_cloud_that_outgrows_the_pair_pool_between_frames(N):
+    """vp_bin fills the lists into the pool as allocated while the host still waits for the totals (launch_bin); a frame whose cloud
+    does not fit must be re-launched after the reallocation, and a smaller cloud afterwards must not see the larger one's lists.  N = 4:
+    the one-workgroup scan of small grids (lists sorted ahead of the wait as well); N = 12: the tiled scan."""
+    scenes = [S.make_scene("g", dims=(N, 16, P, 48, 40), seed=70 + i) for i, P in enumerate((12, 2500, 40, 9000, 40))]
+    g = E.Engine(scenes[0].config(), exact=True, early_out=False)
+    for sc in scenes:
+        o = O.Oracle(sc.config())
+        for x in (o, g):
+            x.set_frame(sc.light_to_world, sc.grid_center)
+            x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+            x.fill(sc.fill_params())
+        co = o.bin_counts()
+        np.testing.assert_array_equal(co, g.bin_counts())
+        assert o.stats()["pairs"] == g.stats()["pairs"] and o.stats()["max_pairs_per_mv"] == g.stats()["max_pairs_per_mv"]
+        for zz, yy, xx in list(zip(*np.nonzero(co)))[::3]:
+            assert np.array_equal(o.read_brick(xx, yy, zz).view(np.uint16), g.read_brick(xx, yy, zz).view(np.uint16)), (xx, yy, zz)
+        np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+        assert np.abs(o.raymarch(sc.camera(), sc.raymarch_params()) - g.raymarch(sc.camera(), sc.raymarch_params())).max() <= 1e-3
+        o.close()
+
+
 def test_composite_kernel():
     sc = S.make_scene("T0")
     g = E.Engine(sc.config())

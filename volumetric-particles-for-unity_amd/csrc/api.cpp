@@ -308,6 +308,9 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
         } else if (rc) return fail(rc);
     }
 #endif
+    if (hipHostMalloc((void**)&c->h_meta_host, sizeof(DevMeta), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->d_meta_host, c->h_meta_host, 0) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(VP_ERR_HIP); }
+    *c->h_meta_host = DevMeta{};
     if (hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_chain_err, c->h_chain_err, 0) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(VP_ERR_HIP); }
     *c->h_chain_err = 0;
@@ -336,6 +339,7 @@ void vp_destroy_single(vp_ctx* c)
                    c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_tile_curve, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo, c->d_occmask};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
+    if (c->h_meta_host) (void)hipHostFree(c->h_meta_host);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_image_ready) (void)hipEventDestroy(c->ev_image_ready);
     if (c->ev_image_copied) (void)hipEventDestroy(c->ev_image_copied);

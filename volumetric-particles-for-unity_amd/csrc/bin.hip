@@ -96,11 +96,14 @@ k_extract(const uint8_t* __restrict__ raw, int P, vp_particle_layout lay, PsysCo
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_bin(const float4* __restrict__ ws4, int P, GridConsts g, const float* __restrict__ mvPos,
-      int* __restrict__ count_or_cursor, const int* __restrict__ offsets, int* __restrict__ ids, float* __restrict__ rec)
+      int* __restrict__ count_or_cursor, const int* __restrict__ offsets, int* __restrict__ ids, float* __restrict__ rec,
+      const DevMeta* __restrict__ ahead_meta, int ahead_cap)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int p = (int)(t / BIN_LANES), sub = (int)(t % BIN_LANES);
     if (p >= P) return;
+    // scatter launched AHEAD of the host's look at the totals (launch_bin): it only runs if the lists fit the pool as allocated
+    if (MODE == 1 && ahead_meta && (unsigned)ahead_meta->pairs > (unsigned)ahead_cap) return;
     const float4 w = ws4[p];
     if (MODE == 0 && sub == 0) {
         // B = W2P_linear * (_LightForward * oneVoxelSize): how far one slice step moves a voxel in this particle's
@@ -227,7 +230,7 @@ k_scan_prefix(TileTotals* __restrict__ totals, int ntiles)
 __global__ void __launch_bounds__(SCAN_TILE)
 k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, const TileTotals* __restrict__ totals, int ntiles,
              int prefixed, int* __restrict__ offsets, int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor,
-             DevMeta* __restrict__ meta)
+             DevMeta* __restrict__ meta, DevMeta* __restrict__ host_meta)
 {
     __shared__ long long sh[48];
     __shared__ long long s_base[3];
@@ -266,8 +269,52 @@ k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, con
     if ((int)blockIdx.x == ntiles - 1 && threadIdx.x == SCAN_TILE - 1) {
         const long long total = base_pairs + a;
         offsets[n3] = (int)total;
-        meta->occupied = base_occ + b; meta->pairs = total > 2147483647LL ? -1 : (int)total; meta->max_pairs = gmax;
-        meta->unsorted_lists = 0;
+        const DevMeta r{base_occ + b, total > 2147483647LL ? -1 : (int)total, gmax, 0};
+        *meta = r;
+        *host_meta = r;                                                      // pinned host memory: no copy command for 16 bytes
+    }
+}
+
+// Grids of at most SCAN_TILE metavoxels (the reference's own scene is 10^3): k_scan_tiles + k_scan_write + k_col_ordinal in ONE workgroup
+// and one launch -- at these sizes the three launches were 15 us of a 48 us bin pass that does microseconds of work.
+__global__ void __launch_bounds__(SCAN_TILE)
+k_scan_small(const int* __restrict__ count, int n3, int nxy, int z0, int z1, int* __restrict__ offsets, int* __restrict__ brick_index,
+             int* __restrict__ occ_list, int* __restrict__ cursor, int* __restrict__ ord, int* __restrict__ colcount,
+             DevMeta* __restrict__ meta, DevMeta* __restrict__ host_meta)
+{
+    __shared__ long long sh[48];
+    __shared__ unsigned char s_occ[SCAN_TILE];
+    const int i = threadIdx.x;
+    const int cnt = i < n3 ? count[i] : 0;
+    const int zz = i / nxy;
+    const bool occ = cnt != 0 && zz >= z0 && zz < z1;                       // VPR.cs:511
+    s_occ[i] = occ ? 1 : 0;
+    long long a = cnt;
+    int b = occ ? 1 : 0, m = cnt;
+    block_scan3(a, b, m, sh);                                               // (its barriers also publish s_occ)
+    if (i < n3) {
+        offsets[i] = (int)(a - cnt);
+        cursor[i] = 0;
+        const int slot = b - (occ ? 1 : 0);
+        brick_index[i] = occ ? slot : -1;
+        if (occ) {
+            occ_list[slot] = i;
+            const int col = i - zz * nxy;
+            int n = 0;
+            for (int z = z0; z < zz; ++z) n += s_occ[z * nxy + col];
+            ord[i] = n;                                                     // position among the column's occupied metavoxels (k_col_ordinal)
+        }
+        if (i < nxy) {
+            int n = 0;
+            for (int z = z0; z < z1; ++z) n += s_occ[z * nxy + i];
+            colcount[i] = n;
+        }
+    }
+    if (i == SCAN_TILE - 1) {
+        offsets[n3] = (int)a;
+        const DevMeta r{b, a > 2147483647LL ? -1 : (int)a, m, 0};
+        *meta = r;
+        *host_meta = r;
     }
 }
 
@@ -275,9 +322,12 @@ k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, con
 #define SORT_CAP 4096
 __global__ void __launch_bounds__(256)
 k_sort_lists(const int* __restrict__ occ_list, const int* __restrict__ offsets, const int* __restrict__ in,
-             int* __restrict__ out, DevMeta* __restrict__ meta)
+             int* __restrict__ out, DevMeta* __restrict__ meta, int ahead_cap)
 {
     __shared__ int s_ids[SORT_CAP];
+    // launched ahead of the host's look at the totals (ahead_cap >= 0): one workgroup per metavoxel of the grid, those past the occupied
+    // count leave; nothing runs if the lists do not fit the pool
+    if (ahead_cap >= 0 && ((int)blockIdx.x >= meta->occupied || (unsigned)meta->pairs > (unsigned)ahead_cap)) return;
     const int mi = occ_list[blockIdx.x];
     const int off = offsets[mi], n = offsets[mi + 1] - off;
     if (n > SORT_CAP) {      // pathological list (> 4096 particles in one MV): the same rank sort straight from global memory
@@ -338,7 +388,7 @@ int launch_z_histogram(vp_ctx* c, int* d_hist)
     VP_HIP(hipMemsetAsync(d_hist, 0, (size_t)g.Nz * sizeof(int), c->stream));
     if (c->P > 0)
         hipLaunchKernelGGL(k_bin<2>, dim3((unsigned)(((size_t)c->P * BIN_LANES + 255) / 256)), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, d_hist,
-                           (const int*)nullptr, (int*)nullptr, c->d_rec);
+                           (const int*)nullptr, (int*)nullptr, c->d_rec, (const DevMeta*)nullptr, 0);
     VP_HIP(hipGetLastError());
     return VP_OK;
 }
@@ -352,23 +402,43 @@ int launch_bin(vp_ctx* c)
     VP_HIP(hipEventRecord(c->ev[0][0], c->stream));
     if (c->P > 0) {
         hipLaunchKernelGGL(k_bin<0>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_count,
-                           (const int*)nullptr, (int*)nullptr, c->d_rec);
+                           (const int*)nullptr, (int*)nullptr, c->d_rec, (const DevMeta*)nullptr, 0);
     }
-    const int ntiles = (n3 + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
-                       (TileTotals*)c->d_scan_totals);
-    const int prefixed = ntiles > SCAN_DIRECT_TILES ? 1 : 0;
-    if (prefixed) hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(SCAN_TILE), 0, c->stream, (TileTotals*)c->d_scan_totals, ntiles);
-    hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
-                       (const TileTotals*)c->d_scan_totals, ntiles, prefixed, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta);
-    hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 3) / 4), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
+    const bool small = n3 <= SCAN_TILE;
+    if (small) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1, c->d_offsets, c->d_brick_index,
+                           c->d_occ_list, c->d_cursor, c->d_ord, c->d_colcount, c->d_meta, c->d_meta_host);
+    } else {
+        const int ntiles = (n3 + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
+                           (TileTotals*)c->d_scan_totals);
+        const int prefixed = ntiles > SCAN_DIRECT_TILES ? 1 : 0;
+        if (prefixed) hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(SCAN_TILE), 0, c->stream, (TileTotals*)c->d_scan_totals, ntiles);
+        hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
+                           (const TileTotals*)c->d_scan_totals, ntiles, prefixed, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta,
+                           c->d_meta_host);
+        hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 3) / 4), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
+    }
+    // The totals are needed on the host to size the pair and brick pools.  While the host waits for them the GPU already fills the lists
+    // into the pool as it stands: both kernels check the totals against its capacity themselves and do nothing if it is too small (a
+    // frame whose cloud outgrew the pool: re-launched below after the reallocation).  Large grids sort after the wait -- one workgroup
+    // per metavoxel of the GRID is only free while that is a thousand.
+    const int ahead_cap = (int)(c->pairs_cap < 2147483647u ? c->pairs_cap : 2147483647u);
+    const bool ahead = c->P > 0 && c->pairs_cap > 0, ahead_sort = ahead && small;
+    if (ahead) {
+        hipLaunchKernelGGL(k_bin<1>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_cursor,
+                           (const int*)c->d_offsets, c->d_ids_tmp, c->d_rec, (const DevMeta*)c->d_meta, ahead_cap);
+        if (ahead_sort)
+            hipLaunchKernelGGL(k_sort_lists, dim3(n3), dim3(256), 0, c->stream, c->d_occ_list, c->d_offsets,
+                               (const int*)c->d_ids_tmp, c->d_ids, c->d_meta, ahead_cap);
+    }
     VP_HIP(hipGetLastError());
-    // totals are needed on the host to size the pair and brick pools
-    VP_HIP(hipMemcpyAsync(&c->h_meta, c->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, c->stream));
     VP_HIP(hipStreamSynchronize(c->stream));
+    c->h_meta = *c->h_meta_host;
     if (c->h_meta.pairs < 0)
         return vp_fail(c, VP_ERR_UNSUPPORTED, "vp_bin: more than INT_MAX (particle, metavoxel) pairs; the CSR offsets are 32-bit");
     const size_t pairs = (size_t)c->h_meta.pairs;
+    bool scattered = ahead, sorted = ahead_sort;
     if (pairs > c->pairs_cap) {
         if (c->d_ids) VP_HIP(hipFree(c->d_ids));
         if (c->d_ids_tmp) VP_HIP(hipFree(c->d_ids_tmp));
@@ -376,12 +446,15 @@ int launch_bin(vp_ctx* c)
         c->pairs_cap = pairs + pairs / 4 + 1024;
         VP_HIP(hipMalloc(&c->d_ids, c->pairs_cap * sizeof(int)));
         VP_HIP(hipMalloc(&c->d_ids_tmp, c->pairs_cap * sizeof(int)));
+        scattered = sorted = false;                        // the kernels launched ahead saw that the pool was too small and left
     }
     if (c->P > 0 && pairs > 0) {
-        hipLaunchKernelGGL(k_bin<1>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_cursor,
-                           (const int*)c->d_offsets, c->d_ids_tmp, c->d_rec);
-        hipLaunchKernelGGL(k_sort_lists, dim3(c->h_meta.occupied), dim3(256), 0, c->stream, c->d_occ_list, c->d_offsets,
-                           (const int*)c->d_ids_tmp, c->d_ids, c->d_meta);
+        if (!scattered)
+            hipLaunchKernelGGL(k_bin<1>, dim3(nb), dim3(256), 0, c->stream, c->d_ws, c->P, g, c->d_mvPos, c->d_cursor,
+                               (const int*)c->d_offsets, c->d_ids_tmp, c->d_rec, (const DevMeta*)nullptr, 0);
+        if (!sorted)
+            hipLaunchKernelGGL(k_sort_lists, dim3(c->h_meta.occupied), dim3(256), 0, c->stream, c->d_occ_list, c->d_offsets,
+                               (const int*)c->d_ids_tmp, c->d_ids, c->d_meta, -1);
         VP_HIP(hipGetLastError());
     }
     VP_HIP(hipEventRecord(c->ev[0][1], c->stream));

@@ -146,6 +146,8 @@ struct vp_ctx {
     size_t pairs_cap = 0;
     int* d_onecol = nullptr;      // [2] one MV column index (per-metavoxel fill) + the cube-map range flag
     DevMeta* d_meta = nullptr;
+    DevMeta* h_meta_host = nullptr;   // the same four words in pinned host memory, written by the scan kernel itself ...
+    DevMeta* d_meta_host = nullptr;   // ... through this device address (no copy command between the scan and the host's wait)
     void* d_scan_totals = nullptr; // [ceil(N^3 / 1024)] per-tile totals of the two-launch scan
     DevMeta h_meta{};
 
