@@ -387,53 +387,16 @@ __device__ __forceinline__ F4 draw_order_color(int order_index, int num_covered)
     return sel == 0 ? F4{0.f, v, 0.f, 1.f} : sel == 1 ? F4{0.f, 0.f, v, 1.f} : F4{v, 0.f, 0.f, 1.f};
 }
 
-// Everything the march needs per frame in ONE launch over all N^3 cells (it was four memsets and a kernel over the occupied metavoxels):
-// the translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld of every occupied metavoxel (VPR.cs:774-778,
-// same operation order as the matrix product the reference does per draw) into mvtrans[slot] and into the cell's record, "empty" records for the other cells, the
-// occupancy bitmask rows (the thread of a row's first cell builds the word), brick_hit[slot] = 0, the sample counter = 0.
-__global__ void __launch_bounds__(256)
-k_rm_prepare(RmConsts k, const int* __restrict__ brick_index, const float* __restrict__ mvPos, int n3, float4* __restrict__ mvtrans,
-             float4* __restrict__ cellinfo /* nullable */, uint32_t* __restrict__ occmask /* nullable */, int* __restrict__ brick_hit,
-             unsigned long long* __restrict__ samples)
-{
-    const int mi = blockIdx.x * 256 + threadIdx.x;
-    if (mi == 0) *samples = 0ull;
-    if (mi >= n3) return;
-    const int slot = brick_index[mi];
-    if (slot >= 0) {
-        const float mx = mvPos[3 * mi], my = mvPos[3 * mi + 1], mz = mvPos[3 * mi + 2];
-        float tr[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float a = k.inv_rows[r * 3], b = k.inv_rows[r * 3 + 1], c = k.inv_rows[r * 3 + 2];
-            const float t = -((a * mx + b * my) + c * mz);
-            tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + c * k.c2w_t[2]) + t * k.c2w_t[3];
-        }
-        mvtrans[slot] = make_float4(tr[0], tr[1], tr[2], 0.f);
-        if (cellinfo) cellinfo[mi] = make_float4(tr[0], tr[1], tr[2], __int_as_float(slot));
-        brick_hit[slot] = 0;
-    } else if (cellinfo) {
-        const float e = __int_as_float(-1);
-        cellinfo[mi] = make_float4(e, e, e, e);                          // the walk reads the record of every cell it crosses
-    }
-    if (occmask && mi % k.Nx == 0) {
-        uint32_t word = 0;
-        for (int x = 0; x < k.Nx; ++x) word |= (brick_index[mi + x] >= 0 ? 1u : 0u) << x;
-        occmask[mi / k.Nx] = word;                                       // row (zz, yy)
-    }
-}
-
 // Dispatch order of the screen super-tiles (64x32 px): most expensive first, so that the long rays are not what the
 // tail of the launch waits for (per-wave work spans 0 .. ~600 samples; dispatched in raster order ~25 % of the wave
 // slots idle).  Cost estimate per super-tile = fraction of the ray inside occupied metavoxels (x its length in the owned
 // part of the grid), from four of its rays; each ray is probed at 64 points by the 64 lanes of one wave, so the estimate
-// costs ONE dependent load.  k_tile_rank then rank-sorts in LDS.  Scheduling only: the image does not depend on the order.
+// costs ONE dependent load.  Run by the trailing workgroups of k_rm_prepare (one per super-tile); k_tile_rank then rank-sorts in LDS.  Scheduling only: the image does not depend on the order.
 #define RM_ORDER_MAX 8192
-__global__ void __launch_bounds__(256)
-k_tile_cost(RmConsts k, const int* __restrict__ brick_index, int sgx, float* __restrict__ cost_out)
+__device__ __forceinline__ void tile_cost(const RmConsts& k, const int* __restrict__ brick_index, int sgx, float* __restrict__ cost_out, const int sti)
 {
     __shared__ float part[4];
-    const int sti = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int SW = 16 << VPFX_RM_LX, SH = 16 << VPFX_RM_LY;                    // super-tile size in pixels
     const float colf = fminf((float)((sti % sgx) * SW + SW / 4 + (SW / 2) * (wave & 1)), (float)k.W - 1.f);
     const float rowf = fminf((float)((sti / sgx) * SH + SH / 4 + (SH / 2) * (wave >> 1)), (float)k.H - 1.f);
@@ -472,6 +435,45 @@ k_tile_cost(RmConsts k, const int* __restrict__ brick_index, int sgx, float* __r
     if (lane == 0) part[wave] = c;
     __syncthreads();
     if (threadIdx.x == 0) cost_out[sti] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// Everything the march needs per frame in ONE launch over all N^3 cells (it was four memsets and a kernel over the occupied metavoxels):
+// the translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld of every occupied metavoxel (VPR.cs:774-778,
+// same operation order as the matrix product the reference does per draw) into mvtrans[slot] and into the cell's record, "empty" records for the other cells, the
+// occupancy bitmask rows (the thread of a row's first cell builds the word), brick_hit[slot] = 0, the sample counter = 0.
+__global__ void __launch_bounds__(256)
+k_rm_prepare(RmConsts k, const int* __restrict__ brick_index, const float* __restrict__ mvPos, int n3, float4* __restrict__ mvtrans,
+             float4* __restrict__ cellinfo /* nullable */, uint32_t* __restrict__ occmask /* nullable */, int* __restrict__ brick_hit,
+             unsigned long long* __restrict__ samples, int nprep, int sgx, float* __restrict__ cost_out)
+{
+    // workgroups past the cells' own: one super-tile's cost estimate each (tile_cost; it reads brick_index only -- nothing this launch writes).
+    // One launch instead of two: a frame of the reference's scene is 0.24 ms and a launch is 4 us of it.
+    if ((int)blockIdx.x >= nprep) { tile_cost(k, brick_index, sgx, cost_out, (int)blockIdx.x - nprep); return; }
+    const int mi = blockIdx.x * 256 + threadIdx.x;
+    if (mi == 0) *samples = 0ull;
+    if (mi >= n3) return;
+    const int slot = brick_index[mi];
+    if (slot >= 0) {
+        const float mx = mvPos[3 * mi], my = mvPos[3 * mi + 1], mz = mvPos[3 * mi + 2];
+        float tr[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float a = k.inv_rows[r * 3], b = k.inv_rows[r * 3 + 1], c = k.inv_rows[r * 3 + 2];
+            const float t = -((a * mx + b * my) + c * mz);
+            tr[r] = ((a * k.c2w_t[0] + b * k.c2w_t[1]) + c * k.c2w_t[2]) + t * k.c2w_t[3];
+        }
+        mvtrans[slot] = make_float4(tr[0], tr[1], tr[2], 0.f);
+        if (cellinfo) cellinfo[mi] = make_float4(tr[0], tr[1], tr[2], __int_as_float(slot));
+        brick_hit[slot] = 0;
+    } else if (cellinfo) {
+        const float e = __int_as_float(-1);
+        cellinfo[mi] = make_float4(e, e, e, e);                          // the walk reads the record of every cell it crosses
+    }
+    if (occmask && mi % k.Nx == 0) {
+        uint32_t word = 0;
+        for (int x = 0; x < k.Nx; ++x) word |= (brick_index[mi + x] >= 0 ? 1u : 0u) << x;
+        occmask[mi / k.Nx] = word;                                       // row (zz, yy)
+    }
 }
 
 // rank of 64 super-tiles per workgroup: wave w counts, for each of them, the costlier tiles among the w-th sixteenth of all
@@ -585,7 +587,7 @@ k_raymarch(RmConsts k, const int* __restrict__ brick_index, const uint2* __restr
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed dispatch order; used for speed only), and each XCD
     // has its own L2.  Screen tiles are grouped into super-tiles (64x32 px, about one brick's footprint); a super-tile is
     // rendered entirely by one XCD, so a brick is pulled into ~2-4 L2s instead of all eight, while consecutive super-tiles
-    // of the dispatch order (cost-sorted, see k_tile_cost) alternate XCDs (load balance).
+    // of the dispatch order (cost-sorted, see tile_cost) alternate XCDs (load balance).
     constexpr int LX = VPFX_RM_LX, LY = VPFX_RM_LY, WPS = 4 << (LX + LY);            // waves per super-tile
     constexpr int SW = 16 << LX, SH = 16 << LY;                                     // super-tile size in pixels
     const int sgx = (k.W + SW - 1) / SW, sgy = (k.H + SH - 1) / SH;
@@ -1264,6 +1266,20 @@ k_composite(const float4* __restrict__ particles, float4* __restrict__ scene, si
     scene[i] = d;
 }
 
+// Cost-sorted dispatch order or raster order?  The order only matters when the launch does not fit the GPU at once: an image whose waves are
+// all resident together (two per SIMD counted, the least any instantiation gets) ends with its slowest wave whatever the order, and the
+// estimate + sort are 8 us of such a frame (C1: 1 024 waves).
+bool rm_ordered(const vp_ctx* c, const RmConsts& k)
+{
+#ifdef VPFX_RM_NO_ORDER
+    return false;
+#else
+    const int nsuper = rm_num_super_tiles(k.W, k.H);
+    const long long waves = (long long)nsuper * (4 << (VPFX_RM_LX + VPFX_RM_LY));
+    return nsuper <= RM_ORDER_MAX && waves > (long long)c->num_cus * 8;
+#endif
+}
+
 template <int NV, bool PARTIAL, bool WRAP, bool FLAGS, bool GREY = false>
 void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho)
 {
@@ -1271,9 +1287,8 @@ void launch_rm_variant(vp_ctx* c, const RmConsts& k, float* d_over, float* d_und
     const int* order = nullptr;
     int order_len = nsuper;
 #ifndef VPFX_RM_NO_ORDER
-    if (nsuper <= RM_ORDER_MAX) {
-        float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));
-        hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, rm_super_tiles_x(k.W), cost);
+    if (rm_ordered(c, k)) {
+        float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));     // written by k_rm_prepare's trailing workgroups
 #if VPFX_AB
         if (c->rm_xcd_affine && c->d_tile_curve) {
             const int cap = rm_order_cap(nsuper);
@@ -1297,9 +1312,8 @@ void launch_rm_flat(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under,
 {
     const int nsuper = rm_num_super_tiles(k.W, k.H);
     const int* order = nullptr;
-    if (nsuper <= RM_ORDER_MAX) {
+    if (rm_ordered(c, k)) {
         float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));
-        hipLaunchKernelGGL(k_tile_cost, dim3(nsuper), dim3(256), 0, c->stream, k, c->d_brick_index, rm_super_tiles_x(k.W), cost);
         hipLaunchKernelGGL(k_tile_rank, dim3((nsuper + 63) / 64), dim3(1024), 0, c->stream, cost, nsuper, c->d_tile_order);
         order = c->d_tile_order;
     }
@@ -1370,15 +1384,23 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
     if (k.occ_lds && !c->d_occmask) VP_HIP(hipMalloc((void**)&c->d_occmask, VPFX_RM_OCC_WORDS * sizeof(uint32_t)));
 #endif
     c->brick_hit_n = nocc;
-    // one launch prepares the frame: translations, per-cell records, occupancy rows, cleared hit flags and sample counter (k_rm_prepare)
-    hipLaunchKernelGGL(k_rm_prepare, dim3((unsigned)((c->n3 + 255) / 256)), dim3(256), 0, c->stream, k, c->d_brick_index, c->d_mvPos, (int)c->n3,
-                       c->d_mvtrans, c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr, c->d_brick_hit, c->d_samples);
+    // one launch prepares the frame: translations, per-cell records, occupancy rows, cleared hit flags and sample counter, and -- its trailing
+    // workgroups -- the super-tiles' cost estimates for the dispatch order (k_rm_prepare).  The stage's start event sits in front of it:
+    // the estimate used to be a launch of its own inside the timed stage.
+    VP_HIP(hipEventRecord(c->ev[2][0], c->stream));
+    {
+        const int nprep = (int)((c->n3 + 255) / 256), nsuper = rm_num_super_tiles(k.W, k.H);
+        const bool ordered = rm_ordered(c, k);
+        float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));
+        hipLaunchKernelGGL(k_rm_prepare, dim3((unsigned)(nprep + (ordered ? nsuper : 0))), dim3(256), 0, c->stream, k, c->d_brick_index, c->d_mvPos,
+                           (int)c->n3, c->d_mvtrans, c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr, c->d_brick_hit, c->d_samples,
+                           nprep, rm_super_tiles_x(k.W), cost);
+    }
     if (nocc > 0) {
         if (k.flags & VP_RM_SHOW_DRAW_ORDER)
             hipLaunchKernelGGL(k_order_index, dim3((nocc + 255) / 256), dim3(256), 0, c->stream, k, c->d_occ_list, c->d_brick_index, c->d_rank,
                                nocc, c->d_mvtrans);
     }
-    VP_HIP(hipEventRecord(c->ev[2][0], c->stream));
     switch (k.nv) {
     case 16: launch_rm_nv<16>(c, k, d_over, d_under, early_out, ho); break;
     case 32: launch_rm_nv<32>(c, k, d_over, d_under, early_out, ho); break;
