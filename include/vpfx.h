@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define VPFX_ABI_VERSION 4   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
+#define VPFX_ABI_VERSION 5   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
                                 3: vp_config device list (multi-GPU fan-out inside the library, RCCL), VP_ERR_RCCL, Unity plugin entry points
                                 4: same struct layouts; new: vp_config.reserved[2] = exchange time-out of a fan-out context (abort instead of hang),
-                                   VP_MULTI_TEST_HOOKS / VP_MULTI_TEST_DROP_SEND, VP_RM_NO_EARLY_OUT, vp_exchange_plan, vp_unity_clear_slot, vp_unity_register_output_fd */
+                                   VP_MULTI_TEST_HOOKS / VP_MULTI_TEST_DROP_SEND, VP_RM_NO_EARLY_OUT, vp_exchange_plan, vp_unity_clear_slot, vp_unity_register_output_fd
+                                5: same struct layouts; new: the particle source (vp_emitter_*) */
 
 typedef enum vp_status {
     VP_OK = 0,
@@ -457,6 +458,35 @@ int  vp_unity_last_status(int32_t slot, uint64_t* events_run);
  * event per frame should also not touch the arrays of the description (particles, the read-back buffer) while
  * vp_unity_last_status().events_run is behind the number of events it has issued. */
 int  vp_unity_clear_slot(int32_t slot);
+
+/* ---- particle source -----------------------------------------------------------------------------------------------
+ * The reference's input is a Unity ParticleSystem (scene "Particle System Demo", Assets/Volumetric_Particle_System.unity:2264-2620: cone
+ * shape type 4 with angle 10 deg and radius 0.5, 10 particles / s, lifetime 6 s, speed 3, size 4, random start rotation, angular velocity
+ * 0.0698 rad/s, at most 60 particles) whose GetParticles array BinParticlesToMetavoxels reads (VPR.cs:412-413).  For hosts without Unity
+ * (examples/, bench.py --config DEMO, the tests) the library carries an emitter with those parameters: host code, deterministic (own
+ * PCG32 stream -- Unity's is closed source), simulated in the system's LOCAL space like the reference's.  It needs no device and no vp_ctx. */
+typedef struct vp_emitter vp_emitter;
+typedef struct vp_emitter_config {
+    uint64_t seed;
+    float rate;                  /* particles per second                      EmissionModule scene:2512-2556 (10)    */
+    float lifetime;              /* seconds = startLifetime of every particle InitialModule  scene:2272-2497 (6)     */
+    float speed;                 /* start speed along the cone                                               (3)     */
+    float size;                  /* start size = DIAMETER (VPR.cs:425)                                        (4)     */
+    float cone_angle_deg;        /* ShapeModule type 4                        scene:2498-2511                (10)    */
+    float cone_radius;           /* radius of the cone's base disc                                            (0.5)   */
+    float angular_velocity_deg;  /* degrees per second                        RotationModule scene:2587-2621 (4)     */
+    int32_t max_particles;       /* live particles never exceed this          numParticlesEmitted            (60)    */
+    int32_t reserved[6];
+} vp_emitter_config;
+void vp_emitter_default_config(vp_emitter_config* cfg);        /* the demo scene's values (the numbers in parentheses above), seed 7 */
+int  vp_emitter_create(const vp_emitter_config* cfg, vp_emitter** out);
+void vp_emitter_destroy(vp_emitter* em);
+/* Advance by dt seconds: move / age / retire, then emit what the rate owes.  Returns the live count (>= 0) or a negative vp_status. */
+int  vp_emitter_step(vp_emitter* em, float dt);
+int  vp_emitter_count(const vp_emitter* em);
+/* Write the live particles (oldest first) as records of `layout` (each zeroed, then position, size, rotation -- degrees or radians as the
+ * layout says --, lifetime, startLifetime): the array vp_bin / vp_upload_particles take.  Returns the records written (<= capacity). */
+int  vp_emitter_write_particles(const vp_emitter* em, void* particles_out, int32_t capacity, const vp_particle_layout* layout);
 
 /* ---- parity probes / stats ------------------------------------------------------------------ */
 int  vp_get_mv_positions(vp_ctx* ctx, float* pos_out /* [Nz][Ny][Nx][3] */);

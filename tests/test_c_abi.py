@@ -13,7 +13,7 @@ from vpfx_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "volumetric-particles-for-unity_amd")
-STRUCTS = ["vp_config", "vp_particle_layout", "vp_fill_params", "vp_camera", "vp_raymarch_params", "vp_obb", "vp_stats", "vp_multi_info", "vp_xop"]
+STRUCTS = ["vp_config", "vp_particle_layout", "vp_fill_params", "vp_camera", "vp_raymarch_params", "vp_obb", "vp_stats", "vp_multi_info", "vp_xop", "vp_emitter_config"]
 
 
 def _cc(args, **kw):
@@ -40,9 +40,9 @@ def test_header_is_c99_and_struct_layouts_match_the_ctypes_mirror(tmp_path):
             assert int(out[f"{name}.{field}"]) == getattr(st, field).offset, f"{name}.{field}"
 
 
-def _build_demo(tmp_path):
-    exe = tmp_path / "demo_frame"
-    r = _cc([os.path.join(ROOT, "examples", "demo_frame.c"), "-L", PKG, "-lvpfx", "-lm", f"-Wl,-rpath,{PKG}", "-o", str(exe)])
+def _build_demo(tmp_path, name="demo_frame"):
+    exe = tmp_path / name
+    r = _cc(["-D_POSIX_C_SOURCE=199309L", os.path.join(ROOT, "examples", name + ".c"), "-L", PKG, "-lvpfx", "-lm", f"-Wl,-rpath,{PKG}", "-o", str(exe)])
     assert r.returncode == 0, r.stderr
     return str(exe)
 
@@ -52,6 +52,32 @@ def test_demo_links_and_fails_loudly_without_a_device(tmp_path):
     assert r.returncode in (0, 3), r.stdout + r.stderr                 # 3 = VP_ERR_NO_DEVICE reported, no CPU fallback
     if r.returncode == 3:
         assert "no CPU fallback" in r.stderr
+
+
+def test_demo_scene_links_and_fails_loudly_without_a_device(tmp_path):
+    r = subprocess.run([_build_demo(tmp_path, "demo_scene"), "2", "64", "48"], capture_output=True, text=True)
+    assert r.returncode in (0, 3), r.stdout + r.stderr
+    if r.returncode == 3:
+        assert "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_demo_scene_from_c_is_the_scene_the_python_binding_renders(tmp_path):
+    """examples/demo_scene.c: the reference's scene + the library's emitter, bin + fill every 2nd frame, from plain C.  The particle cloud is the
+    one scene.make_demo_scene builds (same emitter, same warm-up), so the binned statistics of frame 0 must be the binding's."""
+    from vpfx_amd import engine as E, scene as S
+    r = subprocess.run([_build_demo(tmp_path, "demo_scene"), "5", "256", "192"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nums = {k: float(v) for k, v in re.findall(r"(\w+) (-?[\d.]+)", r.stdout)}
+    sc, em, _ = S.make_demo_scene(width=256, height=192)
+    em.step(1.0 / 30.0)                                                  # the C loop steps the emitter before frame 0's refill
+    parts = em.particles()
+    eng = E.Engine(sc.config())
+    eng.set_frame(sc.light_to_world, sc.grid_center)
+    eng.bin(parts, sc.layout, sc.psys_local_to_world)
+    st = eng.stats()
+    assert nums["particles"] == len(parts) and nums["occupied_mv"] == st["occupied_mv"] > 0 and nums["pairs"] == st["pairs"]
+    assert 0.01 < nums["covered"] < 1.0 and nums["sum_rgb"] > 0
 
 
 def _lcg_scene(P):

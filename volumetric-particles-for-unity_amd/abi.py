@@ -34,7 +34,7 @@ VP_BRICKS_RGBA16F, VP_BRICKS_GREY_ZPAIR = 0, 1
 VP_CUBEMAP_F32 = 0
 VP_CUBEMAP_R8 = 1
 
-VPFX_ABI_VERSION = 4
+VPFX_ABI_VERSION = 5
 
 STATUS_NAMES = {
     0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
@@ -164,6 +164,13 @@ class vp_obb(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("axes", C.c_float * 9), ("half_extent", C.c_float * 3)]
 
 
+class vp_emitter_config(C.Structure):
+    """Parameters of the library's particle source (the demo scene's ParticleSystem, scene:2264-2620)."""
+    _fields_ = [("seed", C.c_uint64), ("rate", C.c_float), ("lifetime", C.c_float), ("speed", C.c_float), ("size", C.c_float),
+                ("cone_angle_deg", C.c_float), ("cone_radius", C.c_float), ("angular_velocity_deg", C.c_float), ("max_particles", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
 class vp_stats(C.Structure):
     _fields_ = [
         ("particles", C.c_int64),
@@ -209,6 +216,7 @@ EXPORTED_SYMBOLS = [
     "vp_raymarch_partial_handoff_device", "vp_read_zsamples",
     "vp_get_multi_info", "vp_rebalance", "vp_rccl_unique_id", "vp_plan_slabs", "vp_blend_plan", "vp_exchange_plan",
     "vp_unity_render_event_func", "vp_unity_set_frame_desc", "vp_unity_register_output", "vp_unity_register_output_fd", "vp_unity_last_status", "vp_unity_clear_slot",
+    "vp_emitter_default_config", "vp_emitter_create", "vp_emitter_destroy", "vp_emitter_step", "vp_emitter_count", "vp_emitter_write_particles",
 ]
 class vp_xop(C.Structure):
     """One operation of the image exchange's message schedule (vp_exchange_plan)."""

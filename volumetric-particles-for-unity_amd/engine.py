@@ -55,6 +55,11 @@ def lib():
         for name in abi.EXPORTED_SYMBOLS:
             getattr(L, name)       # AttributeError if the header and the library ever disagree
         L.vp_destroy.restype = None
+        L.vp_emitter_destroy.restype = None
+        L.vp_emitter_destroy.argtypes = [C.c_void_p]
+        L.vp_emitter_default_config.restype = None
+        L.vp_emitter_count.argtypes = [C.c_void_p]
+        L.vp_emitter_step.argtypes = [C.c_void_p, C.c_float]
         _lib = L
     return _lib
 

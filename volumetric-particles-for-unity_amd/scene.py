@@ -257,52 +257,51 @@ def make_box(center, half_extent, rot3=None) -> abi.vp_obb:
 # The demo scene of the reference (Assets/Volumetric_Particle_System.unity) -- SURVEY section 8(f) row 3
 # ---------------------------------------------------------------------------------------------------------------
 class DemoEmitter:
-    """A deterministic stand-in for the demo's Unity ParticleSystem ("Particle System Demo", scene:2264-2620):
-    cone shape (angle 10 deg, radius 0.5), 10 particles/s, lifetime 6 s, speed 3, size 4, random start rotation,
-    angular velocity 0.0698 rad/s, at most `max_particles` (scene: 60, slider 0-128), simulated in LOCAL space.
-    Unity's own emitter/RNG is closed source, so this reproduces the documented parameters, not its random stream.
+    """The demo's Unity ParticleSystem ("Particle System Demo", scene:2264-2620) as the library emits it: a thin binding of the C ABI's
+    particle source (`vp_emitter_*`, csrc/emitter.cpp: cone angle 10 deg / radius 0.5, 10 particles/s, lifetime 6 s, speed 3, size 4, random
+    start rotation, 4 deg/s, at most `max_particles` (scene: 60), simulated in LOCAL space).  No arithmetic here.
     `particles()` returns the live particles in the ParticleSystem.Particle layout the C ABI consumes."""
 
-    def __init__(self, seed=7, rate=10.0, lifetime=6.0, speed=3.0, size=4.0, cone_deg=10.0, radius=0.5,
-                 ang_vel_deg=4.0, max_particles=60):
-        self.rng = np.random.default_rng(seed)
-        self.rate, self.lifetime, self.speed, self.size = rate, lifetime, speed, size
-        self.cone, self.radius, self.ang_vel, self.max = math.radians(cone_deg), radius, ang_vel_deg, max_particles
-        self.t, self.acc = 0.0, 0.0
-        self.pos = np.zeros((0, 3)); self.vel = np.zeros((0, 3)); self.rot = np.zeros(0); self.life = np.zeros(0)
+    def __init__(self, seed=7, **overrides):
+        from . import engine
+        self.L = engine.lib()
+        cfg = abi.vp_emitter_config()
+        self.L.vp_emitter_default_config(C.byref(cfg))
+        cfg.seed = seed
+        for k, v in overrides.items():
+            assert hasattr(cfg, k), k
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.L.vp_emitter_create(C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise ValueError(f"vp_emitter_create -> {abi.STATUS_NAMES.get(rc, rc)}")
+        self.layout = particle_layout(False)
 
     def step(self, dt):
-        self.t += dt
-        self.pos = self.pos + self.vel * dt
-        self.rot = self.rot + self.ang_vel * dt
-        self.life = self.life - dt
-        keep = self.life > 0
-        self.pos, self.vel, self.rot, self.life = self.pos[keep], self.vel[keep], self.rot[keep], self.life[keep]
-        self.acc += self.rate * dt
-        n = min(int(self.acc), self.max - len(self.life))
-        self.acc -= int(self.acc)
-        if n > 0:
-            r = self.radius * np.sqrt(self.rng.random(n))
-            phi = self.rng.uniform(0, 2 * math.pi, n)
-            base = np.stack([r * np.cos(phi), r * np.sin(phi), np.zeros(n)], -1)
-            tilt = self.cone * (r / self.radius)                      # edge of the base emits along the cone surface
-            d = np.stack([np.sin(tilt) * np.cos(phi), np.sin(tilt) * np.sin(phi), np.cos(tilt)], -1)
-            self.pos = np.concatenate([self.pos, base])
-            self.vel = np.concatenate([self.vel, d * self.speed])
-            self.rot = np.concatenate([self.rot, self.rng.uniform(0, 360, n)])
-            self.life = np.concatenate([self.life, np.full(n, self.lifetime)])
+        n = self.L.vp_emitter_step(self.h, C.c_float(dt))
+        if n < 0:
+            raise ValueError(f"vp_emitter_step -> {abi.STATUS_NAMES.get(n, n)}")
+        return n
 
-    def particles(self):
-        p = np.zeros(len(self.life), dtype=PARTICLE_DTYPE)
-        p["position"] = self.pos.astype(np.float32)
-        p["velocity"] = self.vel.astype(np.float32)
-        p["size"] = self.size
-        p["rotation"] = np.mod(self.rot, 360.0).astype(np.float32)    # degrees (the C# property)
-        p["lifetime"] = self.life.astype(np.float32)
-        p["startLifetime"] = self.lifetime
-        p["axisOfRotation"] = (0.0, 0.0, 1.0)
-        p["color"] = 0xFFFFFFFF
+    def particles(self, layout=None):
+        lay = self.layout if layout is None else layout
+        n = self.L.vp_emitter_count(self.h)
+        p = np.zeros(n, dtype=PARTICLE_DTYPE)
+        got = self.L.vp_emitter_write_particles(self.h, p.ctypes.data_as(C.c_void_p), n, C.byref(lay))
+        assert got == n, (got, n)
         return p
+
+    def close(self):
+        if self.h:
+            self.L.vp_emitter_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make_demo_scene(width=1024, height=768, warm_seconds=6.0, seed=7):
