@@ -1,6 +1,6 @@
 """Ray-march kernel time of the benchmark scene (C3) from several view directions / rolls: the brick rows run along the grid's x axis, so the
 L1 cost of the trilinear footprint loads depends on how screen rows map onto the grid.  GPU only:  gpurun -- python scripts/view_sweep.py"""
-import os, sys, importlib
+import os, sys, importlib, hashlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -34,7 +34,8 @@ def main():
             eng.raymarch(sc.camera(), sc.raymarch_params(), out=img)
             st = eng.stats()
             ts.append(eng.last_kernel_ms(2))
-        print(f"{name:34s}: k_raymarch {np.median(ts[1:]):.3f} ms, {st['samples'] / 1e6:.0f} M samples, {st['samples'] / np.median(ts[1:]) / 1e6:.1f} Gsamples/s", flush=True)
+        print(f"{name:34s}: k_raymarch {np.median(ts[1:]):.3f} ms, {st['samples'] / 1e6:.0f} M samples, {st['samples'] / np.median(ts[1:]) / 1e6:.1f} Gsamples/s, "
+              f"image {hashlib.sha256(img.tobytes()).hexdigest()[:12]}", flush=True)
 
 if __name__ == "__main__":
     main()
