@@ -170,8 +170,7 @@ int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp
     if ((rp->flags & VP_RM_SHOW_DRAW_ORDER) && (c->g.z0 != 0 || c->g.z1 != c->g.Nz))
         return vp_fail(c, VP_ERR_UNSUPPORTED, "VP_RM_SHOW_DRAW_ORDER needs a whole-grid context (mvCount runs over every slab)");
     hl_build_rm_consts(c, cam, rp, k);
-    hl_build_rank(c, cam, c->h_rank);
-    VP_HIP(hipMemcpyAsync(c->d_rank, c->h_rank, (size_t)c->g.Nx * c->g.Ny * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // (the draw order of the (yy, xx) columns, VPR.cs:613-632, is ranked on the device by k_rm_prepare: no per-frame copy command)
     if (rp->scene_depth) {
         if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
         VP_HIP(hipMemcpyAsync(c->d_scene_depth, rp->scene_depth, (size_t)c->cfg.width * c->cfg.height * sizeof(float),
@@ -181,7 +180,7 @@ int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp
         if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
         int rc = launch_scene_depth(c, cam, c->d_scene_depth); if (rc) return rc;
     }
-    // h_rank / scene_depth are pageable: the async copies above have already consumed them on return
+    // scene_depth is pageable: the async copy above has already consumed it on return
     return VP_OK;
 }
 
@@ -268,10 +267,9 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
     // identity frame until vp_set_frame
     memset(c->L, 0, sizeof c->L); c->L[0] = c->L[5] = c->L[10] = c->L[15] = 1.f;
     c->h_mvPos = (float*)malloc(c->n3 * 3 * sizeof(float));
-    c->h_rank = (int*)malloc((size_t)cfg->num_mv[0] * cfg->num_mv[1] * sizeof(int));
     int rc = VP_OK;
     auto fail = [&](int code) { g_vp_create_error = c->err; vp_destroy_single(c); return code; };
-    if (!c->h_mvPos || !c->h_rank) { c->err = "vp_create: host allocation failed"; return fail(VP_ERR_OOM); }
+    if (!c->h_mvPos) { c->err = "vp_create: host allocation failed"; return fail(VP_ERR_OOM); }
     hl_build_grid(c);
     if ((rc = ensure_device(c))) return fail(rc);
     if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c->num_cus < 1) c->num_cus = 256;
@@ -285,7 +283,7 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
         (rc = dev_alloc(c, &c->d_lightmap, lightmap_elems(c))) || (rc = dev_alloc(c, &c->d_rank, nxy)) ||
         (rc = dev_alloc(c, &c->d_image, image_elems(c))) || (rc = dev_alloc(c, &c->d_samples, 1)) ||
         (rc = dev_alloc(c, &c->d_zsamples, (size_t)VPFX_ZPROF_COPIES * cfg->num_mv[2])) ||
-        (rc = dev_alloc(c, &c->d_cam_rows, 12)) || (rc = dev_alloc(c, &c->d_tile_order, (size_t)rm_order_ints(rm_num_super_tiles(cfg->width, cfg->height)) + rm_num_super_tiles(cfg->width, cfg->height) + 8)))
+        (rc = dev_alloc(c, &c->d_tile_order, (size_t)rm_order_ints(rm_num_super_tiles(cfg->width, cfg->height)) + rm_num_super_tiles(cfg->width, cfg->height) + 8)))
         return fail(rc);
 #if VPFX_AB
     {
@@ -336,7 +334,7 @@ void vp_destroy_single(vp_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream); else (void)hipDeviceSynchronize();
     void* dev[] = {c->d_mvPos, c->d_raw, c->d_ws, c->d_rec, c->d_count, c->d_offsets, c->d_cursor, c->d_brick_index,
                    c->d_occ_list, c->d_ids_tmp, c->d_ids, c->d_onecol, c->d_work_counter, c->d_ord, c->d_colcount, c->d_chain, c->d_cube_u8, c->d_meta, c->d_scan_totals, c->d_bricks, c->d_dens_ao,
-                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_cam_rows, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_tile_curve, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo, c->d_occmask};
+                   c->d_lightmap, c->d_cubequads, c->d_depthmap, c->d_occluders, c->d_mvtrans, c->d_brick_hit, c->d_rank, c->d_tile_order, c->d_tile_curve, c->d_image, c->d_scene_depth, c->d_samples, c->d_zsamples, c->d_cellinfo, c->d_occmask};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     if (c->h_meta_host) (void)hipHostFree(c->h_meta_host);
@@ -344,7 +342,7 @@ void vp_destroy_single(vp_ctx* c)
     if (c->ev_image_ready) (void)hipEventDestroy(c->ev_image_ready);
     if (c->ev_image_copied) (void)hipEventDestroy(c->ev_image_copied);
     for (int s = 0; s < 4; ++s) for (int j = 0; j < 2; ++j) if (c->ev[s][j]) (void)hipEventDestroy(c->ev[s][j]);
-    free(c->h_mvPos); free(c->h_rank);
+    free(c->h_mvPos);
     delete c;
 }
 

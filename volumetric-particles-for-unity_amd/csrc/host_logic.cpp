@@ -135,24 +135,6 @@ int hl_z_boundary(const vp_ctx* c, const vp_camera* cam)
     return std::min(std::max(zb, -1), g.Nz - 1);
 }
 
-// rank[yy*Nx+xx] = position of (xx,yy) in the ASCENDING distance list (stable on ties, list built yy-major).
-// Phase A (OVER) walks ranks descending, phase B (UNDER) ascending.                  VPR.cs:613-632
-void hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank)
-{
-    const GridConsts& g = c->g;
-    const int nxy = g.Nx * g.Ny;
-    std::vector<float> key(nxy);
-    for (int i = 0; i < nxy; ++i) {
-        const float* p = c->h_mvPos + 3 * (size_t)i;             // zz = 0 slice positions for every zz
-        const float dx = p[0] - cam->cam_pos[0], dy = p[1] - cam->cam_pos[1], dz = p[2] - cam->cam_pos[2];
-        key[i] = (dx * dx + dy * dy) + dz * dz;
-    }
-    std::vector<int> idx(nxy);
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
-    for (int r = 0; r < nxy; ++r) rank[idx[r]] = r;
-}
-
 void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, RmConsts* k)
 {
     const GridConsts& g = c->g;
@@ -162,6 +144,7 @@ void hl_build_rm_consts(const vp_ctx* c, const vp_camera* cam, const vp_raymarch
     k->zB = hl_z_boundary(c, cam);
     k->steps = rp->steps_per_mv; k->soft = rp->soft_distance;
     k->flags = rp->flags;
+    for (int i = 0; i < 3; ++i) k->cam_world[i] = cam->cam_pos[i];
     k->num_covered = c->h_meta.occupied;                                     // numMetavoxelsCovered  VPR.cs:515, 755
     k->aspect = (float)k->W / (float)k->H;                                   // RM.shader:190
     k->neg_inv_tan = -(1.0f / (float)std::tan((double)cam->fov_y * 0.5));    // RM.shader:193

@@ -9,6 +9,8 @@
 
 namespace {
 
+struct CamRows { float r[12]; };       // rows of cameraToWorld's upper 3 x 4
+
 // ray (o, d) vs oriented box: entry / exit parameters; false if missed.  d need not be normalised.
 __device__ __forceinline__ bool ray_obb(const vp_obb& b, float ox, float oy, float oz, float dx, float dy, float dz, float& t0, float& t1)
 {
@@ -55,9 +57,10 @@ k_light_depth(GridConsts g, const vp_obb* __restrict__ boxes, int n, float nearz
 }
 
 __global__ void __launch_bounds__(256)
-k_scene_depth(int W, int H, float aspect, float neg_inv_tan, float nearc, float farc, const float* __restrict__ c2w /* 12: rows */,
+k_scene_depth(int W, int H, float aspect, float neg_inv_tan, float nearc, float farc, const CamRows cam /* cameraToWorld, rows, by value */,
               const vp_obb* __restrict__ boxes, int n, float* __restrict__ out)
 {
+    const float* c2w = cam.r;
     const int col = blockIdx.x * 16 + (threadIdx.x & 15), row = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (col >= W || row >= H) return;
     float dx = (2.0f * ((float)col + 0.5f) / (float)W - 1.0f) * aspect;
@@ -90,16 +93,13 @@ int launch_light_depth(vp_ctx* c, float nearz, float farz, float cam_dist, float
 int launch_scene_depth(vp_ctx* c, const vp_camera* cam, float* d_out)
 {
     const int W = c->cfg.width, H = c->cfg.height;
-    float rows[12];
+    CamRows rows;                                         // a kernel argument: no copy command and no host wait in front of the frame's launches
     for (int r = 0; r < 3; ++r)
-        for (int k = 0; k < 4; ++k) rows[r * 4 + k] = cam->camera_to_world[k * 4 + r];
-    float* d_rows = c->d_cam_rows;
-    VP_HIP(hipMemcpyAsync(d_rows, rows, sizeof rows, hipMemcpyHostToDevice, c->stream));
-    VP_HIP(hipStreamSynchronize(c->stream));              // `rows` is a stack temporary
+        for (int k = 0; k < 4; ++k) rows.r[r * 4 + k] = cam->camera_to_world[k * 4 + r];
     const float aspect = (float)W / (float)H;
     const float nit = -(1.0f / (float)tan((double)cam->fov_y * 0.5));
     hipLaunchKernelGGL(k_scene_depth, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, c->stream, W, H, aspect, nit, cam->near_clip,
-                       cam->far_clip > 0.f ? cam->far_clip : 3.0e38f, (const float*)d_rows, c->d_occluders, c->n_occluders, d_out);
+                       cam->far_clip > 0.f ? cam->far_clip : 3.0e38f, rows, c->d_occluders, c->n_occluders, d_out);
     VP_HIP(hipGetLastError());
     return VP_OK;
 }

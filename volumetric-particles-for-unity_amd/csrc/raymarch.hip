@@ -437,6 +437,52 @@ __device__ __forceinline__ void tile_cost(const RmConsts& k, const int* __restri
     if (threadIdx.x == 0) cost_out[sti] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// rank[yy * Nx + xx] = position of the column (xx, yy) in the ASCENDING list of squared distances of its zz = 0 metavoxel from the camera -- the
+// reference's List<MetavoxelSortData>.Sort by distance (VPR.cs:613-632; stable on ties, the list is built yy-major): phase A (OVER) walks the
+// ranks descending, phase B (UNDER) ascending.  Ranked here, in k_rm_prepare's last workgroups (the host used to sort and upload it: one
+// pageable copy command per frame in front of the frame's launches): thread i counts the columns that sort in front of column i.
+#define RM_RANK_LDS 4096
+#define RM_RANK_COLS 64          // columns ranked per workgroup: wave w of the four counts over the w-th quarter of the keys
+__device__ __forceinline__ void column_rank(const RmConsts& k, const float* __restrict__ mvPos, int* __restrict__ rank_out, const int blk)
+{
+    __shared__ __attribute__((aligned(16))) float keys[RM_RANK_LDS];
+    __shared__ int partial[RM_RANK_COLS];
+    const int nxy = k.Nx * k.Ny;
+    auto key_of = [&](int j) -> float {
+        const float dx = mvPos[3 * j] - k.cam_world[0], dy = mvPos[3 * j + 1] - k.cam_world[1], dz = mvPos[3 * j + 2] - k.cam_world[2];
+        return (dx * dx + dy * dy) + dz * dz;
+    };
+    const int i = blk * RM_RANK_COLS + ((int)threadIdx.x & (RM_RANK_COLS - 1)), chunk = (int)threadIdx.x / RM_RANK_COLS;
+    if (nxy > RM_RANK_LDS) {                              // a grid wider than the LDS table: wave 0 recomputes the keys from global memory
+        if (chunk == 0 && i < nxy) {
+            const float ki = key_of(i);
+            int r = 0;
+            for (int j = 0; j < nxy; ++j) { const float kj = key_of(j); r += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+            rank_out[i] = r;
+        }
+        return;
+    }
+    const int npad = (nxy + 3) & ~3;
+    for (int j = threadIdx.x; j < npad; j += 256) keys[j] = j < nxy ? key_of(j) : 3.0e38f;      // padding never sorts in front of a column
+    if (threadIdx.x < RM_RANK_COLS) partial[threadIdx.x] = 0;
+    __syncthreads();
+    if (i < nxy) {
+        const int per = ((npad + 15) / 16) * 4, j0 = chunk * per, j1 = min(npad, j0 + per);
+        const float ki = keys[i];
+        int r = 0;
+        for (int j = j0; j < j1; j += 4) {
+            const float4 kj = *reinterpret_cast<const float4*>(&keys[j]);
+            r += (kj.x < ki || (kj.x == ki && j < i)) ? 1 : 0;
+            r += (kj.y < ki || (kj.y == ki && j + 1 < i)) ? 1 : 0;
+            r += (kj.z < ki || (kj.z == ki && j + 2 < i)) ? 1 : 0;
+            r += (kj.w < ki || (kj.w == ki && j + 3 < i)) ? 1 : 0;
+        }
+        atomicAdd(&partial[threadIdx.x & (RM_RANK_COLS - 1)], r);
+    }
+    __syncthreads();
+    if (chunk == 0 && i < nxy) rank_out[i] = partial[threadIdx.x];
+}
+
 // Everything the march needs per frame in ONE launch over all N^3 cells (it was four memsets and a kernel over the occupied metavoxels):
 // the translation column of _CameraToMetavoxel = TRS(mvPos, lightRot, s).inverse * cameraToWorld of every occupied metavoxel (VPR.cs:774-778,
 // same operation order as the matrix product the reference does per draw) into mvtrans[slot] and into the cell's record, "empty" records for the other cells, the
@@ -444,8 +490,9 @@ __device__ __forceinline__ void tile_cost(const RmConsts& k, const int* __restri
 __global__ void __launch_bounds__(256)
 k_rm_prepare(RmConsts k, const int* __restrict__ brick_index, const float* __restrict__ mvPos, int n3, float4* __restrict__ mvtrans,
              float4* __restrict__ cellinfo /* nullable */, uint32_t* __restrict__ occmask /* nullable */, int* __restrict__ brick_hit,
-             unsigned long long* __restrict__ samples, int nprep, int sgx, float* __restrict__ cost_out)
+             unsigned long long* __restrict__ samples, int nprep, int sgx, float* __restrict__ cost_out, int ncost, int* __restrict__ rank_out)
 {
+    if ((int)blockIdx.x >= nprep + ncost) { column_rank(k, mvPos, rank_out, (int)blockIdx.x - nprep - ncost); return; }
     // workgroups past the cells' own: one super-tile's cost estimate each (tile_cost; it reads brick_index only -- nothing this launch writes).
     // One launch instead of two: a frame of the reference's scene is 0.24 ms and a launch is 4 us of it.
     if ((int)blockIdx.x >= nprep) { tile_cost(k, brick_index, sgx, cost_out, (int)blockIdx.x - nprep); return; }
@@ -1392,9 +1439,10 @@ int launch_raymarch(vp_ctx* c, const RmConsts& k_in, float* d_over, float* d_und
         const int nprep = (int)((c->n3 + 255) / 256), nsuper = rm_num_super_tiles(k.W, k.H);
         const bool ordered = rm_ordered(c, k);
         float* cost = reinterpret_cast<float*>(c->d_tile_order + rm_order_ints(nsuper));
-        hipLaunchKernelGGL(k_rm_prepare, dim3((unsigned)(nprep + (ordered ? nsuper : 0))), dim3(256), 0, c->stream, k, c->d_brick_index, c->d_mvPos,
+        const int ncost = ordered ? nsuper : 0, nrank = (k.Nx * k.Ny + RM_RANK_COLS - 1) / RM_RANK_COLS;
+        hipLaunchKernelGGL(k_rm_prepare, dim3((unsigned)(nprep + ncost + nrank)), dim3(256), 0, c->stream, k, c->d_brick_index, c->d_mvPos,
                            (int)c->n3, c->d_mvtrans, c->d_cellinfo, k.occ_lds ? c->d_occmask : (uint32_t*)nullptr, c->d_brick_hit, c->d_samples,
-                           nprep, rm_super_tiles_x(k.W), cost);
+                           nprep, rm_super_tiles_x(k.W), cost, ncost, c->d_rank);
     }
     if (nocc > 0) {
         if (k.flags & VP_RM_SHOW_DRAW_ORDER)

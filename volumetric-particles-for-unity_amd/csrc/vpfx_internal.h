@@ -67,6 +67,7 @@ struct RmConsts {
     float c2w_t[4];               // translation column of cameraToWorld (x, y, z, w)
     float c2g[12];                // camera space -> grid space (MV (x,y,z) spans [x,x+1)...), rows (traversal only)
     float camg[3];                // camera position in grid space
+    float cam_world[3];           // camera position in world space (vp_camera.cam_pos): the columns' draw-order keys, k_rm_prepare
     float texScale, texBias;      // texel coordinate = local * (nv - 2b) + (b - 0.5)
     float inv_soft;
     float alpha_cutoff;           // early-out once (1 - dst.a) <= cutoff in the UNDER phase (0 = exact only)
@@ -180,16 +181,14 @@ struct vp_ctx {
     // occluder boxes (scene-occlusion inputs produced on the GPU)
     vp_obb* d_occluders = nullptr;
     int n_occluders = 0, occluders_cap = 0;
-    float* d_cam_rows = nullptr;  // 12 floats
 
     // raymarch
     float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
     size_t mvtrans_cap = 0;
     uint32_t* d_occmask = nullptr; // [Nz][Ny] one bit per cell (Nx <= 32): occupied metavoxels, copied into LDS by k_raymarch for the cell walk
     float4* d_cellinfo = nullptr; // [N^3] (translation, brick slot | -1) per cell: VPFX_RM_CELLINFO A/B variant of the cell walk
-    int* d_rank = nullptr;        // [Ny*Nx]
+    int* d_rank = nullptr;        // [Ny*Nx] draw-order rank of the (yy, xx) columns for this frame's camera (VPR.cs:613-632), written by k_rm_prepare
     int* d_tile_order = nullptr;  // [rm_order_ints + super-tiles] dispatch order of k_raymarch (most expensive first), then the float cost estimates
-    int* h_rank = nullptr;
     float* d_image = nullptr;     // [H][W][4]
     float* d_scene_depth = nullptr;
     unsigned long long* d_samples = nullptr;
@@ -240,7 +239,6 @@ inline int rm_num_super_tiles(int W, int H) { return rm_super_tiles_x(W) * rm_su
 // super-tiles a region can hold, k_tile_regions), then the float cost estimates [nsuper]
 inline int rm_order_cap(int nsuper) { return nsuper / 4 + 2; }
 inline int rm_order_ints(int nsuper) { return 8 * rm_order_cap(nsuper) + 8; }
-void   hl_build_rank(const vp_ctx* c, const vp_camera* cam, int* rank);  //           VPR.cs:613-632
 // slab cut + compositing order of the slabs (host only)
 void   hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms, int rm_groups, int* cuts /* [world + 1] */);
 int    hl_blend_plan(int world, const int* cuts, int zb, int* chain, int* plan_rank, int* plan_which, int* plan_kind, int* straddler);
