@@ -440,9 +440,9 @@ __device__ __forceinline__ void tile_cost(const RmConsts& k, const int* __restri
 // rank[yy * Nx + xx] = position of the column (xx, yy) in the ASCENDING list of squared distances of its zz = 0 metavoxel from the camera -- the
 // reference's List<MetavoxelSortData>.Sort by distance (VPR.cs:613-632; stable on ties, the list is built yy-major): phase A (OVER) walks the
 // ranks descending, phase B (UNDER) ascending.  Ranked here, in k_rm_prepare's last workgroups (the host used to sort and upload it: one
-// pageable copy command per frame in front of the frame's launches): thread i counts the columns that sort in front of column i.
+// pageable copy command per frame in front of the frame's launches): the threads of column i count the columns that sort in front of it.
 #define RM_RANK_LDS 4096
-#define RM_RANK_COLS 64          // columns ranked per workgroup: wave w of the four counts over the w-th quarter of the keys
+#define RM_RANK_COLS 16          // columns ranked per workgroup: its 256 threads form 16 groups, group g counts over the g-th sixteenth of the keys
 __device__ __forceinline__ void column_rank(const RmConsts& k, const float* __restrict__ mvPos, int* __restrict__ rank_out, const int blk)
 {
     __shared__ __attribute__((aligned(16))) float keys[RM_RANK_LDS];
@@ -453,7 +453,7 @@ __device__ __forceinline__ void column_rank(const RmConsts& k, const float* __re
         return (dx * dx + dy * dy) + dz * dz;
     };
     const int i = blk * RM_RANK_COLS + ((int)threadIdx.x & (RM_RANK_COLS - 1)), chunk = (int)threadIdx.x / RM_RANK_COLS;
-    if (nxy > RM_RANK_LDS) {                              // a grid wider than the LDS table: wave 0 recomputes the keys from global memory
+    if (nxy > RM_RANK_LDS) {                              // a grid wider than the LDS table: group 0 recomputes the keys from global memory
         if (chunk == 0 && i < nxy) {
             const float ki = key_of(i);
             int r = 0;
@@ -467,7 +467,8 @@ __device__ __forceinline__ void column_rank(const RmConsts& k, const float* __re
     if (threadIdx.x < RM_RANK_COLS) partial[threadIdx.x] = 0;
     __syncthreads();
     if (i < nxy) {
-        const int per = ((npad + 15) / 16) * 4, j0 = chunk * per, j1 = min(npad, j0 + per);
+        constexpr int NCHUNK = 256 / RM_RANK_COLS;
+        const int per = ((npad + 4 * NCHUNK - 1) / (4 * NCHUNK)) * 4, j0 = chunk * per, j1 = min(npad, j0 + per);
         const float ki = keys[i];
         int r = 0;
         for (int j = j0; j < j1; j += 4) {
