@@ -306,9 +306,9 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
         } else if (rc) return fail(rc);
     }
 #endif
-    if (hipHostMalloc((void**)&c->h_meta_host, sizeof(DevMeta), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&c->h_meta_host, 2 * sizeof(DevMeta), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_meta_host, c->h_meta_host, 0) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(VP_ERR_HIP); }
-    *c->h_meta_host = DevMeta{};
+    c->h_meta_host[0] = c->h_meta_host[1] = DevMeta{};        // [0] the totals, [1].occupied = the sequence word the scan writes behind them
     if (hipHostMalloc((void**)&c->h_chain_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->d_chain_err, c->h_chain_err, 0) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(VP_ERR_HIP); }
     *c->h_chain_err = 0;

@@ -13,6 +13,8 @@
 // per-MV translation.  All acceptance arithmetic follows DESIGN.md section 4 exactly (bit-identical lists).
 #include "vpfx_internal.h"
 
+#include <chrono>
+
 namespace {
 
 __device__ __forceinline__ float rd_f32(const uint8_t* p)
@@ -227,10 +229,19 @@ k_scan_prefix(TileTotals* __restrict__ totals, int ntiles)
     if (threadIdx.x == 0) totals[ntiles] = TileTotals{s_carry[0], (int)s_carry[1], (int)s_carry[2]};
 }
 
+// The totals go straight into pinned, coherent host memory, followed by this frame's sequence number (system-scope release): the host
+// polls that word (launch_bin) and reads the totals a microsecond after the scan has them -- while the kernels launched ahead of its wait
+// (scatter, list sort) still run -- instead of sleeping until the whole stream has drained.
+__device__ __forceinline__ void publish_totals(DevMeta* host_meta, const DevMeta& r, int seq)
+{
+    *host_meta = r;
+    __hip_atomic_store(reinterpret_cast<int*>(host_meta + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void __launch_bounds__(SCAN_TILE)
 k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, const TileTotals* __restrict__ totals, int ntiles,
              int prefixed, int* __restrict__ offsets, int* __restrict__ brick_index, int* __restrict__ occ_list, int* __restrict__ cursor,
-             DevMeta* __restrict__ meta, DevMeta* __restrict__ host_meta)
+             DevMeta* __restrict__ meta, DevMeta* __restrict__ host_meta, int seq)
 {
     __shared__ long long sh[48];
     __shared__ long long s_base[3];
@@ -271,7 +282,7 @@ k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, con
         offsets[n3] = (int)total;
         const DevMeta r{base_occ + b, total > 2147483647LL ? -1 : (int)total, gmax, 0};
         *meta = r;
-        *host_meta = r;                                                      // pinned host memory: no copy command for 16 bytes
+        publish_totals(host_meta, r, seq);                                   // pinned host memory: no copy command for 16 bytes
     }
 }
 
@@ -280,7 +291,7 @@ k_scan_write(const int* __restrict__ count, int n3, int nxy, int z0, int z1, con
 __global__ void __launch_bounds__(SCAN_TILE)
 k_scan_small(const int* __restrict__ count, int n3, int nxy, int z0, int z1, int* __restrict__ offsets, int* __restrict__ brick_index,
              int* __restrict__ occ_list, int* __restrict__ cursor, int* __restrict__ ord, int* __restrict__ colcount,
-             DevMeta* __restrict__ meta, DevMeta* __restrict__ host_meta)
+             DevMeta* __restrict__ meta, DevMeta* __restrict__ host_meta, int seq)
 {
     __shared__ long long sh[48];
     __shared__ unsigned char s_occ[SCAN_TILE];
@@ -314,7 +325,7 @@ k_scan_small(const int* __restrict__ count, int n3, int nxy, int z0, int z1, int
         offsets[n3] = (int)a;
         const DevMeta r{b, a > 2147483647LL ? -1 : (int)a, m, 0};
         *meta = r;
-        *host_meta = r;
+        publish_totals(host_meta, r, seq);
     }
 }
 
@@ -405,9 +416,11 @@ int launch_bin(vp_ctx* c)
                            (const int*)nullptr, (int*)nullptr, c->d_rec, (const DevMeta*)nullptr, 0);
     }
     const bool small = n3 <= SCAN_TILE;
+    const int seq = ++c->bin_seq;                           // this frame's tag of the totals in pinned host memory (never 0 = the initial value)
+    if (c->bin_seq == 0x7fffffff) c->bin_seq = 0;
     if (small) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1, c->d_offsets, c->d_brick_index,
-                           c->d_occ_list, c->d_cursor, c->d_ord, c->d_colcount, c->d_meta, c->d_meta_host);
+                           c->d_occ_list, c->d_cursor, c->d_ord, c->d_colcount, c->d_meta, c->d_meta_host, seq);
     } else {
         const int ntiles = (n3 + SCAN_TILE - 1) / SCAN_TILE;
         hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
@@ -416,7 +429,7 @@ int launch_bin(vp_ctx* c)
         if (prefixed) hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(SCAN_TILE), 0, c->stream, (TileTotals*)c->d_scan_totals, ntiles);
         hipLaunchKernelGGL(k_scan_write, dim3(ntiles), dim3(SCAN_TILE), 0, c->stream, c->d_count, n3, nxy, g.z0, g.z1,
                            (const TileTotals*)c->d_scan_totals, ntiles, prefixed, c->d_offsets, c->d_brick_index, c->d_occ_list, c->d_cursor, c->d_meta,
-                           c->d_meta_host);
+                           c->d_meta_host, seq);
         hipLaunchKernelGGL(k_col_ordinal, dim3((nxy + 3) / 4), dim3(256), 0, c->stream, c->d_brick_index, nxy, g.z0, g.z1, c->d_ord, c->d_colcount);
     }
     // The totals are needed on the host to size the pair and brick pools.  While the host waits for them the GPU already fills the lists
@@ -433,7 +446,23 @@ int launch_bin(vp_ctx* c)
                                (const int*)c->d_ids_tmp, c->d_ids, c->d_meta, ahead_cap);
     }
     VP_HIP(hipGetLastError());
-    VP_HIP(hipStreamSynchronize(c->stream));
+    // wait for the TOTALS, not for the stream: poll the sequence word the scan writes behind them.  The stream is asked now and then (a failed
+    // launch would never publish); after a while the host stops spinning and sleeps on the stream as before (the GPU may be a frame behind).
+    {
+        const volatile int* seq_word = reinterpret_cast<const volatile int*>(c->h_meta_host + 1);
+        const auto t_begin = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spin = 0; !seen; ++spin) {
+            if (__atomic_load_n(const_cast<const int*>(seq_word), __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            if ((spin & 1023u) == 1023u) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) break;                               // everything has run: the totals are there
+                if (q != hipErrorNotReady) return vp_fail(c, VP_ERR_HIP, "vp_bin: %s", hipGetErrorString(q));
+                if (std::chrono::steady_clock::now() - t_begin > std::chrono::microseconds(400)) break;
+            }
+        }
+        if (!seen) VP_HIP(hipStreamSynchronize(c->stream));
+    }
     c->h_meta = *c->h_meta_host;
     if (c->h_meta.pairs < 0)
         return vp_fail(c, VP_ERR_UNSUPPORTED, "vp_bin: more than INT_MAX (particle, metavoxel) pairs; the CSR offsets are 32-bit");

@@ -147,10 +147,11 @@ struct vp_ctx {
     size_t pairs_cap = 0;
     int* d_onecol = nullptr;      // [2] one MV column index (per-metavoxel fill) + the cube-map range flag
     DevMeta* d_meta = nullptr;
-    DevMeta* h_meta_host = nullptr;   // the same four words in pinned host memory, written by the scan kernel itself ...
+    DevMeta* h_meta_host = nullptr;   // the same four words in pinned (coherent) host memory + a sequence word behind them, written by the scan kernel itself ...
     DevMeta* d_meta_host = nullptr;   // ... through this device address (no copy command between the scan and the host's wait)
     void* d_scan_totals = nullptr; // [ceil(N^3 / 1024)] per-tile totals of the two-launch scan
     DevMeta h_meta{};
+    int bin_seq = 0;              // tag of the totals published by this frame's scan (launch_bin polls it in pinned host memory)
 
     // fill
     uint2* d_bricks = nullptr;    // [brick_cap][nv^3] x 8 B: RGBA16F texels, or (bricks_grey) z-pair entries (luminance|density)(z), (luminance|density)(z + 1)
