@@ -20,6 +20,7 @@
 //     fetches: gfx950 has no image/sampler hardware), or -- 8-bit maps, the reference asset's format -- lives in LDS as bytes.
 // Bound: HBM store of the bricks (8 B/voxel) is the roofline; the kernels are limited well before it by VALU issue (k_fill_lds) and by
 // the CU's L1/TA rate of the per-voxel footprint gather (k_fill).
+#include <cstdlib>
 #include <type_traits>
 
 #include "vpfx_internal.h"
@@ -63,6 +64,9 @@ extern "C" __attribute__((visibility("default"))) int vpfx_probe_read(unsigned l
 #endif
 #ifndef VPFX_FILL_CLAIM_PREF
 #define VPFX_FILL_CLAIM_PREF 15      // the slot whose wave fetches the next block (measured at C3: slot 0 / 12 / 15 -> 2.99 / 2.965 / 2.95 ms)
+#endif
+#ifndef VPFX_FILL_MIN_CLAIM_LOG2
+#define VPFX_FILL_MIN_CLAIM_LOG2 2   // small launches: blocks of at least 4 units (= working waves per workgroup, one per SIMD)
 #endif
 #define VPFX_FILL_CLAIM_RING 64      // blocks remembered per workgroup (power of two)
 #ifndef VPFX_FILL_PIPE
@@ -685,7 +689,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restric
 template <int NV, int MODE, int TAB, bool DONE>
 __global__ void __launch_bounds__(64 * VPFX_FILL_LDS_WAVES)
 k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
-           int nitems, FillChain ch)
+           int nitems, FillChain ch, int claim_log2)
 {
     extern __shared__ uint32_t lds_cube[];
 #if VPFX_FILL_CLAIM > 1
@@ -694,13 +698,19 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
     if (threadIdx.x < VPFX_FILL_CLAIM_RING) s_block[threadIdx.x] = 0ull;
     if (threadIdx.x == 64) s_ticket = 0u;
     __syncthreads();
-    if (threadIdx.x == 0) s_block[0] = (1ull << 32) | (unsigned)atomicAdd(p_counter, VPFX_FILL_CLAIM);     // block 0 (in flight during the table copy)
+    if (threadIdx.x == 0) s_block[0] = (1ull << 32) | (unsigned)atomicAdd(p_counter, 1 << claim_log2);     // block 0 (in flight during the table copy)
 #endif
     for (int i = threadIdx.x; i < table_dwords; i += 64 * VPFX_FILL_LDS_WAVES) lds_cube[i] = p_cube_u8[i];
     __syncthreads();
     const unsigned lds_base = (unsigned)(size_t)lds_cube;       // low half of the flat address of an LDS object = its LDS byte offset
     constexpr int T8 = NV / 8, TPC = T8 * T8;                    // 8x8-column tiles per MV column
     const int lane = threadIdx.x & 63;
+#if VPFX_FILL_CLAIM > 1
+    // Small launches (fewer units than the GPU has wave slots: the reference's own scene, config 1) run with SMALLER blocks and as many
+    // working waves per workgroup as a block has units, the other waves leaving once the table is in LDS: 1 248 units are then spread over
+    // every CU at one or two waves per SIMD instead of filling 78 CUs at four (launch_fill_lds_variant picks claim_log2).
+    if ((int)(threadIdx.x >> 6) >= (1 << claim_log2)) return;
+#endif
 #if VPFX_PROBE == 9
     unsigned long long prof_acc[12] = {};
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
@@ -717,11 +727,11 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
         // ticket apart, and a fetched block waits (CLAIM - PREF) tickets at most, so the z-major hand-out the chain relies on is kept:
         // the lowest unfinished unit is either running or in a block whose workgroup's waves all run LOWER units (tickets and blocks both
         // ascend), which finish without waiting for anything unfinished and then draw it.
-        constexpr unsigned CL = VPFX_FILL_CLAIM, PREF = VPFX_FILL_CLAIM_PREF < CL ? VPFX_FILL_CLAIM_PREF : CL - 1;
+        const unsigned CL = 1u << claim_log2, PREF = VPFX_FILL_CLAIM_PREF < CL ? VPFX_FILL_CLAIM_PREF : CL - 1;
         unsigned tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         tk = __builtin_amdgcn_readfirstlane(tk);
-        const unsigned blk = tk / CL, slot = tk % CL;
+        const unsigned blk = tk >> claim_log2, slot = tk & (CL - 1u);
         unsigned long long bw = __hip_atomic_load(&s_block[blk & (VPFX_FILL_CLAIM_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         for (unsigned spins = 0; (unsigned)(bw >> 32) != blk + 1u; ++spins) {
             // a tag beyond the awaited one would mean the ring lapped a wave that sat RING x CLAIM tickets between two instructions: report, never mis-assign
@@ -936,9 +946,19 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     if (nitems == 0) return VP_OK;
     VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     constexpr int WV = VPFX_FILL_LDS_WAVES;
-    const int grid = nitems < WV * c->num_cus ? (nitems + WV - 1) / WV : c->num_cus;   // one persistent workgroup per CU
+    static_assert(VPFX_FILL_CLAIM == 1 || VPFX_FILL_CLAIM == WV, "a full block is one unit per wave of the workgroup");
+    // units per block = working waves per workgroup: the full 16 once there is a block for every CU, else halved until there is (at least
+    // 4 = one wave per SIMD).  Measured (profiles/r04_ab/fill_small_launches_spread_over_all_cus.txt): DEMO / C1 have 1 248 units; blocks of
+    // 16 / 8 / 4 / 2 / 1 -> fill 0.128 / 0.092 / 0.090 / 0.116 / 0.147 ms (DEMO), 0.085 / 0.070 / 0.070 / 0.094 / 0.126 (C1); bit-identical bricks.
+    int claim_log2 = 4;
+    if (VPFX_FILL_CLAIM > 1) while (claim_log2 > VPFX_FILL_MIN_CLAIM_LOG2 && (nitems >> claim_log2) < c->num_cus) --claim_log2;
+#if VPFX_AB
+    { const char* sw = getenv("VPFX_FILL_CLAIM_LOG2"); if (sw && sw[0] >= '0' && sw[0] <= '4') claim_log2 = sw[0] - '0'; }
+#endif
+    const int per = 1 << claim_log2, nblocks = (nitems + per - 1) / per;
+    const int grid = nblocks < c->num_cus ? nblocks : c->num_cus;                      // one persistent workgroup per CU
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WV), bytes, c->stream, c->g, c->fc, FILL_PTR_ARGS(P), (const uint32_t*)c->d_cube_u8,
-                       (int)(bytes / 4), c->d_work_counter, nitems, ch);
+                       (int)(bytes / 4), c->d_work_counter, nitems, ch, claim_log2);
     return VP_OK;
 }
 
