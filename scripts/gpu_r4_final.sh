@@ -1,3 +1,4 @@
+# (before this: python scripts/isa_mix.py profiles/r04_valu_classes.json profiles/r04_isa_mix.json on the final sources -- limiters_json.py prices the class counters with it)
 # round 4, final evidence on the final sources (one GPU call): -m gpu suite, rocprofv3 passes (C3, C5), bench lines, view sweep, fuzz sweep
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r4_final; mkdir -p $OUT

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """What limits the two dominant kernels instead of HBM, as NUMBERS derived from rocprofv3 PMC passes (one rocpd .db per pass), written to
 profiles/limiters_<cfg>_<cubemap>.json under the same kernel-source fingerprint as the traffic file; bench.py reports them as
-`roofline.limiter` only while the fingerprint still matches.  usage: limiters_json.py out.json pass1.db pass2.db ..."""
+`roofline.limiter` only while the fingerprint still matches.  usage: limiters_json.py out.json pass1.db pass2.db ...
+or: limiters_json.py out.json earlier_limiters.json   (recompute the derived figures from the raw counter means an earlier run of this script kept,
+e.g. once profiles/r04_isa_mix.json has been regenerated for the sources that run profiled; the fingerprint stays the one recorded there)"""
 import hashlib, json, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_sources_sha():
@@ -12,7 +14,14 @@ def kernel_sources_sha():
             h.update(fn.encode() + b"\0" + open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
 ctr = {}
-for db in sys.argv[2:]:
+RECORDED_SHA = None
+if len(sys.argv) == 3 and sys.argv[2].endswith(".json"):
+    _old = json.load(open(sys.argv[2]))
+    RECORDED_SHA = _old.get("kernel_sources_sha")
+    for _k, _d in _old.items():
+        if isinstance(_d, dict) and "raw_counter_means_per_launch" in _d:
+            ctr[_k] = dict(_d["raw_counter_means_per_launch"], instantiation=_d["instantiation"])
+for db in ([] if RECORDED_SHA else sys.argv[2:]):
     con = sqlite3.connect(db); cur = con.cursor()
     try:
         cur.execute("select kernel_name, counter_name, avg(value), avg(duration) from counters_collection group by kernel_name, counter_name")
@@ -31,6 +40,8 @@ try:
     if not ISA_MIX: print("profiles/r04_isa_mix.json was made on other kernel sources: no valu_issue fraction (rerun scripts/isa_mix.py)", file=sys.stderr)
 except Exception:
     ISA_MIX = {}
+if RECORDED_SHA and RECORDED_SHA != kernel_sources_sha():
+    sys.exit(f"the counters were measured on kernel sources {RECORDED_SHA}, the tree is at {kernel_sources_sha()}: not re-deriving across sources")
 out = {"kernel_sources_sha": kernel_sources_sha(), "source": "rocprofv3 --pmc passes of the bench command (scripts/gpu_prof_r4.sh)"}
 for k, c in ctr.items():
     g = lambda name: c.get(name)

@@ -261,6 +261,28 @@ def test_draw_order_view_matches_the_oracle(cam_pos):
     assert np.abs(m.RenderMetavoxels(sc.camera()) - io).max() <= 1e-6
 
 
+def test_draw_order_with_exactly_tied_columns():
+    """The columns' draw order is a STABLE sort by distance (VPR.cs:613-632; the list is built yy-major): with an unrotated light and the camera on
+    the grid's axis the mirrored columns are exactly equidistant in f32 (4-way ties on an 8 x 8 grid), so the order among them is decided
+    by the tie rule alone -- ranked on the device (k_rm_prepare: column_rank), compared with the oracle's sort through the draw-order view."""
+    sc = S.make_scene("C1")
+    sc.light_to_world = S.to_colmajor16(S.trs((0.0, 0.0, -44.34), np.eye(3)))
+    D = 0.8 * sc.N[0] * sc.mv_scale
+    sc.set_camera((0.0, 0.0, -D))
+    o, g = both(sc)
+    pos = o.mv_positions()[0].reshape(-1, 3).astype(np.float32)          # the zz = 0 slice: one position per column
+    d = pos - np.asarray(sc.cam_pos, dtype=np.float32)
+    key = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    assert len(np.unique(key)) <= len(key) // 4 + 1                      # the scene really has the ties it is about
+    rp = sc.raymarch_params()
+    rp.flags = abi.VP_RM_SHOW_DRAW_ORDER
+    io, ig = o.raymarch(sc.camera(), rp), g.raymarch(sc.camera(), rp)
+    assert np.abs(io - ig).max() <= 1e-6
+    assert len(np.unique(ig.reshape(-1, 4), axis=0)) > 8
+    img_o, img_g = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(img_o - img_g).max() <= 1e-3
+
+
 def test_draw_order_view_needs_the_whole_grid():
     sc = S.make_scene("T0")
     g = E.Engine(sc.config(slab=(0, 2)))
