@@ -113,6 +113,7 @@ VP_EMIT_API int vp_emitter_step(vp_emitter* e, float dt)
     }
     e->live.resize(w);
     e->acc += c.rate * dt;
+    if (!(e->acc < 16777216.0f)) e->acc = 16777216.0f;      // (more than max_particles can ever take; keeps the conversion below defined)
     const int owed = (int)e->acc;
     e->acc -= (float)owed;
     const int room = c.max_particles - (int)e->live.size();
