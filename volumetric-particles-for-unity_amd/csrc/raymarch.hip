@@ -1324,7 +1324,13 @@ bool rm_ordered(const vp_ctx* c, const RmConsts& k)
 #else
     const int nsuper = rm_num_super_tiles(k.W, k.H);
     const long long waves = (long long)nsuper * (4 << (VPFX_RM_LX + VPFX_RM_LY));
-    return nsuper <= RM_ORDER_MAX && waves > (long long)c->num_cus * 8;
+    // A launch that runs at the memory side's pace (k.wave_lx == 4: the lattice is sparser than the texels, nothing a wave fetches is reused --
+    // config 5) keeps RASTER order: neighbouring super-tiles then run at the same time and the lines their waves share (the halo of every
+    // wave's footprint) are still in a cache when the second one asks, which is worth more than a short tail -- C5 7.63 -> 6.75 ms, every
+    // memory-paced view of the camera sweep -8 ... -13 %; the cost order stays where the kernel is issue-bound (C3 0.944 against 1.014 in
+    // raster order, C2 0.451 against 0.516).  Blocks of 2^n x 2^n super-tiles ranked by cost with raster order inside were worse than both
+    // at C5 (7.50 / 7.65 / 8.29 / 8.05 ms for n = 1..4): profiles/r04_ab/raymarch_dispatch_order_memory_paced.{txt,patch}.
+    return nsuper <= RM_ORDER_MAX && waves > (long long)c->num_cus * 8 && k.wave_lx != 4;
 #endif
 }
 
