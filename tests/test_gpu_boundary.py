@@ -283,6 +283,21 @@ def test_draw_order_with_exactly_tied_columns():
     assert np.abs(img_o - img_g).max() <= 1e-3
 
 
+def test_grid_wider_than_the_on_chip_tables():
+    """72 x 64 columns: more than the 4 096 keys the column ranking keeps in LDS (k_rm_prepare: column_rank recomputes them from global memory)
+    and wider than the 32-bit occupancy rows of the cell walk -- both fall back to their table-free paths; frame and draw order vs the oracle."""
+    sc = S.make_scene("wide", dims=(8, 16, 300, 160, 120))
+    sc.N = (72, 64, 2)
+    o, g = both(sc)
+    assert o.stats()["occupied_mv"] == g.stats()["occupied_mv"] > 20
+    img_o, img_g = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert img_o[..., 3].max() > 0.05 and np.abs(img_o - img_g).max() <= 1e-3
+    rp = sc.raymarch_params()
+    rp.flags = abi.VP_RM_SHOW_DRAW_ORDER
+    io, ig = o.raymarch(sc.camera(), rp), g.raymarch(sc.camera(), rp)
+    assert np.abs(io - ig).max() <= 1e-6
+
+
 def test_draw_order_view_needs_the_whole_grid():
     sc = S.make_scene("T0")
     g = E.Engine(sc.config(slab=(0, 2)))
