@@ -55,7 +55,8 @@ typedef struct vp_ctx vp_ctx;
  * CreateResources (VPR.cs:224-281).  Metavoxels are cubes (the reference assumes it, VPR.cs:422). */
 typedef struct vp_config {
     int32_t num_mv[3];        /* numMetavoxelsX, Y, Z                                  VPR.cs:83 */
-    int32_t num_voxels;       /* numVoxelsInMetavoxel (nv): 16, 32 or 64               VPR.cs:85 */
+    int32_t num_voxels;       /* numVoxelsInMetavoxel (nv): any value in [2, 64], odd ones included (the reference's shader stops at
+                                 NUM_VOXELS = 32, Fill.shader:16); 16 / 32 / 64 run the specialised kernels          VPR.cs:85 */
     int32_t num_border;       /* numBorderVoxels per end                               VPR.cs:86 */
     float   mv_scale;         /* mvScale.x: world size of one metavoxel                VPR.cs:84 */
     int32_t width, height;    /* Screen.width / height (particlesRT extent)            VPR.cs:228 */

@@ -17,6 +17,9 @@ from vpfx_amd import scene as S, engine as E
 from oracle import oracle as O
 
 
+ANY_NV_FIRST_SEED = 1_000_000
+
+
 def rand_quat(rng):
     q = rng.normal(size=4)
     q /= np.linalg.norm(q)
@@ -27,10 +30,15 @@ def make_case_scene(seed):
     """The random scene of one case; returns (scene, rng) with rng positioned for the engine options."""
     rng = np.random.default_rng(seed)
     nv = int(rng.choice([16, 16, 16, 32, 32, 64]))
-    N = int(rng.integers(1, {16: 7, 32: 5, 64: 3}[nv]))
+    if seed >= ANY_NV_FIRST_SEED and rng.random() < 0.6:
+        # second generation of the sweep (round 5): any numVoxelsInMetavoxel the inspector field can hold (VPR.cs:84), odd values
+        # included -- the run-time-nv kernels.  Seeds below ANY_NV_FIRST_SEED keep the scenes of the earlier sweeps (the regression seeds).
+        nv = int(rng.choice([int(rng.integers(2, 33)), int(rng.integers(2, 33)), int(rng.integers(33, 64))]))
+    N = int(rng.integers(1, 7 if nv <= 16 else 5 if nv <= 32 else 3))
     P = int(rng.integers(0, 500)) if rng.random() < 0.85 else int(rng.integers(500, 4000))
     W, H = int(rng.integers(17, 140)), int(rng.integers(9, 100))
     border = int(rng.choice([0, 1, 1, 2]))
+    border = min(border, (nv - 1) // 2)                # 2 * border < nv (vp_create refuses anything else; the reference divides by nv - 2b)
     lo = rng.uniform(0.3, 1.2) if rng.random() < 0.9 else rng.uniform(2.0, 6.0)      # now and then particles larger than a metavoxel
     sc = S.make_scene("fuzz", seed=seed, dims=(N, nv, P, W, H), border=border, fade=int(rng.integers(0, 2)),
                       size_range=(lo, lo + rng.uniform(0.1, 1.2)), rotation_in_radians=bool(rng.integers(0, 2)))

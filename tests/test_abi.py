@@ -93,8 +93,13 @@ def test_bad_arguments_are_rejected_before_touching_a_device():
     h = C.c_void_p()
     assert lib.vp_create(None, C.byref(h)) == abi.VP_ERR_BAD_ARG
     cfg = S.make_scene("T0").config()
-    cfg.num_voxels = 24                                    # not a built brick size
-    assert lib.vp_create(C.byref(cfg), C.byref(h)) == abi.VP_ERR_UNSUPPORTED
+    for bad_nv in (65, 1, 0, -16):                         # [2, 64] is the whole domain (24, 12, 13 ... run the run-time-nv kernels)
+        cfg.num_voxels = bad_nv
+        cfg.num_border = 0
+        assert lib.vp_create(C.byref(cfg), C.byref(h)) in (abi.VP_ERR_UNSUPPORTED, abi.VP_ERR_BAD_ARG)
+    if not _has_gpu():                                     # an accepted voxel count gets as far as looking for a device
+        cfg.num_voxels = 24
+        assert lib.vp_create(C.byref(cfg), C.byref(h)) == abi.VP_ERR_NO_DEVICE
     cfg = S.make_scene("T0").config()
     cfg.num_border = 8                                     # 2b >= nv
     assert lib.vp_create(C.byref(cfg), C.byref(h)) == abi.VP_ERR_BAD_ARG

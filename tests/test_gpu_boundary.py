@@ -171,6 +171,37 @@ def test_per_metavoxel_entry_points_replay_the_reference_loops(cam_pos):
     assert (zb >= 0) == (cam_pos is not None)
 
 
+@pytest.mark.parametrize("nv,border,cam_pos", [(12, 1, (-7.0, 2.0, 1.0)), (24, 0, None), (9, 1, (2.0, 5.0, -1.0)), (40, 2, None)])
+def test_per_metavoxel_entry_points_at_a_run_time_voxel_count(nv, border, cam_pos):
+    """The same replay for voxel counts other than 16 / 32 / 64 (k_fill<.., GEN> column-range kernels, k_raymarch_one<0, ..>; border 0:
+    the wrap of a brick whose edge is not a power of two)."""
+    sc = S.make_scene("fuzz", seed=300 + nv, dims=(3, nv, 90, 72, 56), border=border)
+    sc.set_camera(cam_pos if cam_pos is not None else (6.0, 4.5, -8.0))
+    cam = sc.camera()
+    m = _manager(sc)
+    m.BinParticlesToMetavoxels(sc.particles, sc.layout)
+    m.FillMetavoxels()
+    e = m._engine
+    cnt = e.bin_counts()
+    bricks = {k: e.read_brick(k[2], k[1], k[0]).copy() for k in zip(*np.nonzero(cnt))}
+    assert len(bricks) > 2
+    lm = e.read_lightmap()
+    frame = m.RenderMetavoxels(cam)
+    m.FillMetavoxelsPerDraw()
+    for k, b in bricks.items():
+        assert np.array_equal(e.read_brick(k[2], k[1], k[0]).view(np.uint16), b.view(np.uint16)), k
+    np.testing.assert_array_equal(e.read_lightmap(), lm)
+    per_draw = m.RenderMetavoxelsPerDraw(cam)
+    assert np.abs(per_draw - frame).max() <= 2e-6
+    o = O.Oracle(sc.config())
+    o.set_frame(sc.light_to_world, sc.grid_center)
+    o.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    o.fill(sc.fill_params())
+    io = o.raymarch(cam, sc.raymarch_params())
+    assert np.abs(per_draw - io).max() <= 1e-3
+    assert e.stats()["samples"] == o.stats()["samples"]
+
+
 def test_per_metavoxel_fill_with_an_r8_cubemap_and_a_storage_format_change():
     """vpfx.h: the per-metavoxel fill replays vp_fill within 1 fp16 ulp for R8 cube maps (vp_fill: LDS byte kernel; per metavoxel: float table);
     and a vp_fill_begin that changes the brick storage format (grey ambient -> coloured) clears the pool, so a PARTIAL refill leaves cleared

@@ -100,3 +100,72 @@ def test_survey_anchor_pixels_with_the_reference_displacement_cubemap():
     img = e.raymarch(sc.camera(), sc.raymarch_params())
     assert np.abs(img[g["rows"], g["cols"], 0] - g["r"]).max() <= 5e-5 and np.abs(img[g["rows"], g["cols"], 3] - g["a"]).max() <= 5e-5
     assert abs(float(img[..., 3].mean()) - 0.802) < 1e-3 and abs(float(img[..., :3].max()) - 0.543) < 1e-3
+
+
+# ---- voxel counts other than 16 / 32 / 64 (the run-time-nv kernels: fill_generic.hip, raymarch_generic.hip) -------------------------------
+# numVoxelsInMetavoxel is a public inspector int (VPR.cs:84), used as is for the texture extents (VPR.cs:312-314) and handed to the shaders
+# as the FLOAT uniform _NumVoxels (VPR.cs:527, 722): odd counts divide by two as floats in get_voxel_world_pos (Fill.shader:103).
+def _nv_scene(nv, border, seed=77, N=4, P=260, W=120, H=88, **kw):
+    sc = S.make_scene("fuzz", seed=seed + nv, dims=(N, nv, P, W, H), border=border, **kw)
+    sc.set_camera((5.5, 4.0, -7.5), target=(0.2, -0.1, 0.3))
+    return sc
+
+
+@pytest.mark.parametrize("nv,border", [(8, 1), (12, 1), (24, 2), (13, 1), (5, 0), (20, 0), (4, 1), (40, 3), (63, 1), (3, 1), (2, 0)])
+def test_any_voxel_count_exact_bricks_lightmap_rgba_and_samples(nv, border):
+    sc = _nv_scene(nv, border)
+    o, g = run_pair(sc, exact=True, early_out=False)
+    co = o.bin_counts()
+    np.testing.assert_array_equal(co, g.bin_counts())
+    zz, yy, xx = np.nonzero(co)
+    assert len(zz) > 3
+    for i in range(len(zz)):
+        bo, bg = o.read_brick(xx[i], yy[i], zz[i]), g.read_brick(xx[i], yy[i], zz[i])
+        assert bo.shape == bg.shape == (nv, nv, nv, 4)
+        assert np.array_equal(bo.view(np.uint16), bg.view(np.uint16)), (nv, xx[i], yy[i], zz[i])      # EXACT build: bit-identical
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ig).max() <= 1e-3
+    assert o.stats()["samples"] == g.stats()["samples"] > 0                     # every lattice sample of the oracle, none more
+    assert g.stats()["voxels_filled"] == len(zz) * nv ** 3
+
+
+@pytest.mark.parametrize("nv,border,r8,ambient", [(8, 1, True, None), (12, 1, False, None), (24, 2, True, None), (24, 1, True, (0.1, 0.3, 0.2)),
+                                                   (13, 0, True, None), (48, 1, True, None), (27, 1, False, (0.3, 0.2, 0.1))])
+def test_any_voxel_count_default_math(nv, border, r8, ambient):
+    """Default (fast-reciprocal) fill: <= 1 fp16 ulp; R8 cube maps run the LDS-resident kernel; grey ambient -> z-pair bricks, coloured -> RGBA16F."""
+    sc = _nv_scene(nv, border, seed=91)
+    if r8:
+        sc.cubemap = S.make_cubemap_r8(128 if nv % 2 == 0 else 77)
+    if ambient:
+        sc.ambient = ambient
+    o, g = run_pair(sc)
+    co = o.bin_counts()
+    worst = 0
+    for zz, yy, xx in zip(*np.nonzero(co)):
+        worst = max(worst, int(f16_ulp_diff(o.read_brick(xx, yy, zz), g.read_brick(xx, yy, zz)).max()))
+    assert worst <= 1
+    np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=5e-5, atol=1e-9)
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    assert np.abs(io - ig).max() <= 1e-3
+    from vpfx_amd import abi
+    assert g.stats()["brick_format"] == (abi.VP_BRICKS_GREY_ZPAIR if (ambient is None and border >= 1) else abi.VP_BRICKS_RGBA16F)
+
+
+@pytest.mark.parametrize("nv,border,world", [(12, 1, 2), (24, 2, 3), (7, 0, 2)])
+def test_any_voxel_count_fan_out(nv, border, world):
+    """The split fill (local pass + finish) and the partial-image ray-march at a run-time voxel count: the fan-out inside the library on one GPU."""
+    from vpfx_amd import abi
+    sc = _nv_scene(nv, border, seed=13, N=4, P=300)
+    o, g = run_pair(sc)
+    cam, rp = sc.camera(), sc.raymarch_params()
+    single = g.raymarch(cam, rp)
+    for flags in (abi.VP_MULTI_PEER_COPY, abi.VP_MULTI_PEER_COPY | abi.VP_MULTI_EXCHANGE_ALL_GATHER):
+        mf = E.Engine(sc.config(devices=[0] * world, multi_flags=flags))
+        mf.set_frame(sc.light_to_world, sc.grid_center)
+        mf.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        mf.fill(sc.fill_params())
+        img = mf.raymarch(cam, rp)
+        assert np.abs(img - single).max() <= 1e-4 and np.abs(img - o.raymarch(cam, rp)).max() <= 1e-3
+        np.testing.assert_allclose(mf.read_lightmap(), o.read_lightmap(), rtol=6e-5, atol=1e-9)
+        mf.close()

@@ -231,8 +231,11 @@ int vp_create_single(const vp_config* cfg, vp_ctx** out)
     if (cfg->num_mv[0] < 1 || cfg->num_mv[1] < 1 || cfg->num_mv[2] < 1 || !(cfg->mv_scale > 0.f) || cfg->num_border < 0 ||
         2 * cfg->num_border >= nv || cfg->width < 1 || cfg->height < 1)
         return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: bad grid/screen configuration");
-    if (nv != 16 && nv != 32 && nv != 64)
-        return vp_fail(nullptr, VP_ERR_UNSUPPORTED, "vp_create: num_voxels %d not built (16, 32, 64)", nv);
+    // Any voxel count the reference's inspector field can hold (VPR.cs:84; its shader's column array stops at NUM_VOXELS = 32, Fill.shader:16,
+    // libvpfx at 64): 16 / 32 / 64 run kernels with the count as a compile-time constant, every other value the run-time-nv kernels
+    // (fill_generic.hip, raymarch_generic.hip).
+    if (nv < 2 || nv > 64)
+        return vp_fail(nullptr, VP_ERR_UNSUPPORTED, "vp_create: num_voxels %d outside [2, 64]", nv);
     if ((cfg->reserved[0] != 0 && cfg->reserved[0] != 1) || (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) || cfg->reserved[2] != 0)
         return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: vp_config.reserved = {%d, %d, %d} (0 or the documented switches; an uninitialised struct?)",
                        cfg->reserved[0], cfg->reserved[1], cfg->reserved[2]);

@@ -259,9 +259,15 @@ size_t cube_u8_bytes(int S);                                                    
 int  launch_fill_one(vp_ctx* c, int xx, int yy, int zz);
 int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v);                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
+// fill_generic.hip: the same for a voxel count that is not 16 / 32 / 64 (run-time nv; called by launch_fill / launch_fill_one)
+int  launch_fill_generic(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out, int math, bool lds);
+int  launch_fill_one_generic(vp_ctx* c, const GridConsts& g, int math);
 // raymarch.hip
 int  launch_raymarch(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, const RmHandoff* handoff = nullptr);
 int  launch_raymarch_one(vp_ctx* c, const RmConsts& k, int bi, int mi, int blend_over, int order_index, float* d_img);  // RenderMetavoxel VPR.cs:766
+// raymarch_generic.hip: the march kernels for a voxel count that is not 16 / 32 / 64 (called by launch_raymarch / launch_raymarch_one)
+int  launch_raymarch_generic(vp_ctx* c, const RmConsts& k, float* d_over, float* d_under, int early_out, const RmHandoff& ho);
+int  launch_raymarch_one_generic(vp_ctx* c, const RmConsts& k, const void* brick, const float* tr, int blend_over, int order_index, float* d_img);
 int    launch_blend(vp_ctx* c, const void* const* d_partials, const int32_t* kinds, int n, float* d_out, size_t npix);
 int  launch_composite(vp_ctx* c, const float* d_particles, float* d_scene);
 // api.cpp: the single-device entry points the fan-out calls on its slab contexts
