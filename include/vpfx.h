@@ -102,6 +102,9 @@ typedef struct vp_config {
 #define VP_MULTI_FORCE               8  /* take the fan-out path (threads, RCCL communicator, collectives) even with one rank                 */
 #define VP_MULTI_TEST_DROP_SEND     16  /* TEST HOOK (needs VP_MULTI_TEST_HOOKS + VP_MULTI_PEER_COPY): the last rank silently skips the first message it
                                            should send -- its peers must time out, the context must abort and every call return VP_ERR_RCCL     */
+#define VP_MULTI_TEST_SHARED_DEVICE  32  /* TEST HOOK (needs VP_MULTI_TEST_HOOKS): devices[] may repeat on the RCCL path.  The real librccl refuses a duplicate device;
+                                           the tests' checking stand-in (tests/tools/fake_rccl.cpp, first on LD_LIBRARY_PATH) runs N ranks on one GPU with RCCL's
+                                           in-issue-order matching enforced                                                                     */
 #define VP_MULTI_TEST_HOOKS 0x40000000  /* opt-in for test hooks (any context, single-device ones too): only with this bit does vp_create read the
                                            VPFX_TEST_* environment switches (VPFX_TEST_CHAIN_TIMEOUT=1: the fill's chain watchdog test)           */
 

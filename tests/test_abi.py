@@ -41,7 +41,7 @@ def test_header_constants_match_the_mirror():
             assert getattr(abi, name) == value, name
             checked += 1
     assert checked >= 25, checked
-    for name in ("VP_RM_NO_EARLY_OUT", "VP_MULTI_TEST_HOOKS", "VP_MULTI_TEST_DROP_SEND", "VP_XOP_ALL_GATHER", "VP_XBUF_FINAL", "VPFX_ABI_VERSION"):
+    for name in ("VP_RM_NO_EARLY_OUT", "VP_MULTI_TEST_HOOKS", "VP_MULTI_TEST_DROP_SEND", "VP_MULTI_TEST_SHARED_DEVICE", "VP_XOP_ALL_GATHER", "VP_XBUF_FINAL", "VPFX_ABI_VERSION"):
         assert name in defs and hasattr(abi, name), name
 
 

@@ -7,6 +7,8 @@ cut, the tau all-gather, the saturation hand-off between slab groups, the image 
 The fan-out must reproduce the single context (<= 2e-5) and the oracle (<= 1e-3); with a fully serial hand-off chain the ranks together
 must execute the single GPU's sample count (the reference's one render target sees every metavoxel: VPR.cs:652-711).
 VP_MULTI_FORCE runs the same path with ONE rank on a real RCCL communicator (ncclCommInitAll + all-gather on one GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -30,8 +32,22 @@ def _single(sc, **kw):
     return e, img
 
 
+# VPFX_TEST_RCCL_SHIM=1 (set by tests/test_gpu_rccl_shim.py for a child pytest whose librccl.so.1 is tests/tools/fake_rccl.cpp): the same tests
+# on the library's RCCL branch -- ncclCommInitAll / ncclCommInitRank, grouped ncclSend / ncclRecv, in-place ncclAllGather -- with N ranks on this
+# one GPU (VP_MULTI_TEST_SHARED_DEVICE) and RCCL's in-issue-order matching enforced by the stand-in.
+SHIM = os.environ.get("VPFX_TEST_RCCL_SHIM") == "1"
+_shim_contexts = [0]
+
+
 def _fanout(sc, world, flags=0, groups=0, **kw):
-    return E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY | flags, rm_groups=groups), **kw)
+    if not SHIM:
+        return E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY | flags, rm_groups=groups), **kw)
+    flags |= abi.VP_MULTI_TEST_HOOKS | abi.VP_MULTI_TEST_SHARED_DEVICE
+    _shim_contexts[0] += 1
+    if _shim_contexts[0] % 2:                                   # one process drives every rank: ncclCommInitAll
+        return E.Engine(sc.config(devices=[0] * world, multi_flags=flags, rm_groups=groups), **kw)
+    # the multi-process form, all ranks in this process: ncclGetUniqueId + grouped ncclCommInitRank
+    return E.Engine(sc.config(devices=[0] * world, world_size=world, first_rank=0, multi_flags=flags, rm_groups=groups, rccl_unique_id=E.rccl_unique_id()), **kw)
 
 
 @pytest.mark.parametrize("world,flags", [(2, 0), (4, 0), (3, abi.VP_MULTI_EXCHANGE_ALL_GATHER), (4, abi.VP_MULTI_UNIFORM_SLABS)])
@@ -44,7 +60,7 @@ def test_fanout_matches_single_context_and_oracle(world, flags):
     o = O.Oracle(sc.config())
     assert np.abs(img - _frame(o, sc)).max() <= 1e-3
     info = m.multi_info()
-    assert info["world_size"] == world and info["num_local"] == world and info["rccl_ranks"] == 0
+    assert info["world_size"] == world and info["num_local"] == world and info["rccl_ranks"] == (world if SHIM else 0)
     cuts = info["slab_cuts"]
     assert cuts[0] == 0 and cuts[-1] == sc.N[2] and all(b > a for a, b in zip(cuts, cuts[1:]))
     assert info["exchange"] == ("all_gather" if flags & abi.VP_MULTI_EXCHANGE_ALL_GATHER else "tiles")

@@ -21,6 +21,7 @@ VP_MULTI_EXCHANGE_ALL_GATHER = 2
 VP_MULTI_UNIFORM_SLABS = 4
 VP_MULTI_FORCE = 8
 VP_MULTI_TEST_DROP_SEND = 16       # test hook: the last rank skips its first send (time-out / abort test)
+VP_MULTI_TEST_SHARED_DEVICE = 32   # test hook: devices[] may repeat on the RCCL path (needs the checking stand-in librccl of tests/tools)
 VP_MULTI_TEST_HOOKS = 0x40000000   # opt-in: vp_create honours the VPFX_TEST_* environment switches
 
 VP_RM_QUANTIZE_UNORM8 = 1

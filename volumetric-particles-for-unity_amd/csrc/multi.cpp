@@ -36,6 +36,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -111,6 +112,11 @@ struct Kid {
     int rank = 0, device = 0, index = 0;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
+    // Guards `comm` against the one cross-thread access there is: multi_abort (any thread) takes the communicator away and ncclCommAbort()s it
+    // -- which frees it -- while this rank's own thread may be about to hand it to ncclSend / ncclRecv / ncclAllGather / ncclCommGetAsyncError.
+    // The owner holds the mutex across each RCCL call (they only enqueue work: microseconds); the aborting thread try-locks with a deadline and,
+    // failing that, leaves the communicator to its owner, which sees the abort flag when the call returns (free_kid destroys it then).
+    std::unique_ptr<std::timed_mutex> comm_m{new std::timed_mutex()};
     float* d_tau_all = nullptr;       // [world][LH][LW]: all-gathered slab transmittance maps (own slot written by the local fill pass)
     float* d_img[2] = {nullptr, nullptr};   // partial images of the slab (phase-A composite, phase-B composite), padded to whole pieces
     uint8_t* d_tmaps = nullptr;       // [world][H][W] received hand-off maps of the slabs in front (one byte per pixel, RmHandoff)
@@ -149,6 +155,7 @@ struct vp_multi {
     std::mutex m;
     std::condition_variable cv_go, cv_done;
     std::function<int(Kid&)> job;
+    bool job_exchanges = true;                // the current job contains inter-rank exchanges: an un-voted failure of one rank aborts the context
     uint64_t gen = 0;
     int pending = 0;
     bool quit = false;
@@ -183,8 +190,12 @@ void multi_abort(vp_multi* M, int rank, const std::string& why)
     { std::lock_guard<std::mutex> lk(M->am); M->abort_msg = "rank " + std::to_string(rank) + ": " + why; }
     fprintf(stderr, "[libvpfx] fan-out aborted by rank %d: %s\n", rank, why.c_str());
     if (M->use_rccl && rccl().CommAbort)
-        for (Kid& k : M->kids)
-            if (k.comm) { ncclComm_t cm = k.comm; k.comm = nullptr; (void)rccl().CommAbort(cm); }     // ends the kernels of stuck collectives, frees the communicator
+        for (Kid& k : M->kids) {
+            // ends the kernels of stuck collectives and frees the communicator -- under the kid's lock (see Kid::comm_m)
+            std::unique_lock<std::timed_mutex> lk(*k.comm_m, std::chrono::milliseconds(200));
+            if (!lk.owns_lock()) continue;                   // its owner is inside an RCCL call right now: it finds the abort flag on return
+            if (k.comm) { ncclComm_t cm = k.comm; k.comm = nullptr; (void)rccl().CommAbort(cm); }
+        }
     { std::lock_guard<std::mutex> lk(M->mm); M->mcv.notify_all(); }
     { std::lock_guard<std::mutex> lk(M->bm); M->bcv.notify_all(); }
 }
@@ -207,9 +218,11 @@ int kid_wait(vp_multi* M, Kid& k, const char* what)
         if (e != hipErrorNotReady) { (void)hipGetLastError(); multi_abort(M, k.rank, std::string(what) + ": " + hipGetErrorString(e)); return aborted_fail(M, c); }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
         if (M->aborted.load() && ms > 2000) return aborted_fail(M, c);           // aborted elsewhere and the stream does not drain: give up on it
-        if (M->use_rccl && k.comm && rccl().CommGetAsyncError && (spin & 63) == 63) {
+        if (M->use_rccl && rccl().CommGetAsyncError && (spin & 63) == 63) {
             ncclResult_t ar = ncclSuccess;
-            if (rccl().CommGetAsyncError(k.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+            bool have = false;
+            { std::lock_guard<std::timed_mutex> lk(*k.comm_m); if (k.comm) have = rccl().CommGetAsyncError(k.comm, &ar) == ncclSuccess; }
+            if (have && ar != ncclSuccess && ar != ncclInProgress) {
                 multi_abort(M, k.rank, std::string(what) + ": asynchronous RCCL error: " + rccl().GetErrorString(ar));
                 return aborted_fail(M, c);
             }
@@ -228,16 +241,18 @@ void worker_main(vp_multi* M, int i)
     uint64_t seen = 0;
     for (;;) {
         std::function<int(Kid&)> job;
+        bool exchanges = true;
         {
             std::unique_lock<std::mutex> lk(M->m);
             M->cv_go.wait(lk, [&] { return M->quit || M->gen != seen; });
             if (M->quit) return;
             seen = M->gen;
             job = M->job;
+            exchanges = M->job_exchanges;
         }
         M->kids[i].voted = false;
         const int rc = job(M->kids[i]);
-        if (rc && !M->kids[i].voted) multi_abort(M, M->kids[i].rank, M->kids[i].c->err);      // its peers may be waiting for it in an exchange
+        if (rc && !M->kids[i].voted && exchanges) multi_abort(M, M->kids[i].rank, M->kids[i].c->err);      // its peers may be waiting for it in an exchange
         {
             std::lock_guard<std::mutex> lk(M->m);
             M->kids[i].rc = rc;
@@ -247,18 +262,21 @@ void worker_main(vp_multi* M, int i)
 }
 
 // Run fn on every local rank (SPMD).  One local rank: inline on the calling thread.  Returns the first failure, its message copied to the
-// fan-out context.
-int run_all(vp_multi* M, const std::function<int(Kid&)>& fn)
+// fan-out context.  exchanges: the job contains inter-rank exchanges, so a rank that fails WITHOUT a vote may leave its peers inside one: the
+// context is aborted.  A job without exchanges (frame / particle upload / occluders / sync: plain argument checks and copies per rank) only
+// reports: a VP_ERR_BAD_ARG every rank returns identically must stay recoverable.
+int run_all(vp_multi* M, const std::function<int(Kid&)>& fn, bool exchanges = true)
 {
     if (M->aborted.load()) return aborted_fail(M, M->parent);
     if (M->nlocal == 1) {
         (void)hipSetDevice(M->kids[0].device);
         M->kids[0].voted = false;
         M->kids[0].rc = fn(M->kids[0]);
-        if (M->kids[0].rc && !M->kids[0].voted && M->world > 1) multi_abort(M, M->kids[0].rank, M->kids[0].c->err);   // the other processes find out by their time-outs
+        if (M->kids[0].rc && !M->kids[0].voted && M->world > 1 && exchanges) multi_abort(M, M->kids[0].rank, M->kids[0].c->err);   // the other processes find out by their time-outs
     } else {
         std::unique_lock<std::mutex> lk(M->m);
         M->job = fn;
+        M->job_exchanges = exchanges;
         M->pending = M->nlocal;
         ++M->gen;
         M->cv_go.notify_all();
@@ -302,6 +320,8 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
     if (ops.empty()) return VP_OK;
     if (M->use_rccl) {
         Rccl& R = rccl();
+        std::lock_guard<std::timed_mutex> lk(*k.comm_m);
+        if (!k.comm) return aborted_fail(M, c);             // taken away by multi_abort
         VP_NCCL(R.GroupStart());
         for (const P2P& o : ops) {
             const ncclResult_t r = o.send ? R.Send(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, k.stream) : R.Recv(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, k.stream);
@@ -377,6 +397,8 @@ int all_gather_inplace(vp_multi* M, Kid& k, float* buf, size_t count)
 {
     vp_ctx* c = k.c;
     if (M->use_rccl) {
+        std::lock_guard<std::timed_mutex> lk(*k.comm_m);
+        if (!k.comm) return aborted_fail(M, c);             // taken away by multi_abort
         VP_NCCL(rccl().AllGather(buf + (size_t)k.rank * count, buf, count, ncclFloat, k.comm, k.stream));
         return VP_OK;
     }
@@ -492,6 +514,9 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     const int world = cfg->world_size > 0 ? cfg->world_size : nlocal;
     const int first = cfg->world_size > 0 ? cfg->first_rank : 0;
     const bool loopback = (cfg->multi_flags & VP_MULTI_PEER_COPY) != 0;
+    // TEST HOOK: ranks that share a GPU on the RCCL path -- only a stand-in librccl supports that (tests/tools/fake_rccl.cpp); the real
+    // library refuses a duplicate device in ncclCommInitAll
+    const bool shared_dev_hook = (cfg->multi_flags & VP_MULTI_TEST_HOOKS) && (cfg->multi_flags & VP_MULTI_TEST_SHARED_DEVICE);
     if (first < 0 || first + nlocal > world) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: ranks [%d, %d) outside world_size %d", first, first + nlocal, world);
     if (world > cfg->num_mv[2]) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: %d slabs for %d light-axis slices (at most one rank per slice)", world, cfg->num_mv[2]);
     if (loopback && nlocal != world) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: VP_MULTI_PEER_COPY needs every rank in this process");
@@ -508,7 +533,7 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
     for (int i = 0; i < nlocal; ++i) {
         if (devs[i] < 0) { if (hipGetDevice(&devs[i]) != hipSuccess) devs[i] = 0; }
         if (devs[i] >= ndev) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: device %d of %d", devs[i], ndev);
-        for (int j = 0; j < i && !loopback; ++j)
+        for (int j = 0; j < i && !loopback && !shared_dev_hook; ++j)
             if (devs[j] == devs[i]) return vp_fail(nullptr, VP_ERR_BAD_ARG, "vp_create: device %d listed twice (RCCL needs one GPU per rank; VP_MULTI_PEER_COPY is the one-GPU test hook)", devs[i]);
     }
     if (!loopback && !rccl().load()) return vp_fail(nullptr, VP_ERR_RCCL, "vp_create: %s", rccl().err.c_str());
@@ -627,7 +652,10 @@ void multi_destroy(vp_ctx* P)
 int multi_set_frame(vp_ctx* P, const float* l2w, const float* gc)
 {
     vp_multi* M = P->multi;
-    const int rc = run_all(M, [&](Kid& k) -> int { return vp_set_frame(k.c, l2w, gc); });
+    // (every job starts with a bounded wait for what the previous frame left on the rank's stream -- ranks other than the display rank return
+    //  from vp_raymarch with their exchanges still queued --: the copies and host polls below would otherwise block without a time-out behind an
+    //  exchange whose peer is gone.  One hipStreamQuery when the stream is idle.)
+    const int rc = run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_set_frame (previous frame's exchanges)"); return rw ? rw : vp_set_frame(k.c, l2w, gc); }, false);
     if (!rc) { P->have_frame = true; P->binned = P->filled = false; }
     return rc;
 }
@@ -637,9 +665,10 @@ int multi_upload_particles(vp_ctx* P, const void* particles, int32_t count, cons
     vp_multi* M = P->multi;
     // every rank bins ALL particles against its own slab: the array goes to every device (the copies of different devices overlap)
     const int rc = run_all(M, [&](Kid& k) -> int {
-        int r = api_upload_particles(k.c, particles, count, lay, psys_l2w, false);
+        int r = kid_wait(M, k, "vp_upload_particles (previous frame's exchanges)");
+        if (!r) r = api_upload_particles(k.c, particles, count, lay, psys_l2w, false);
         return r ? r : api_stream_sync(k.c);
-    });
+    }, false);
     if (!rc) { P->have_particles = true; P->binned = P->filled = false; }
     return rc;
 }
@@ -652,12 +681,16 @@ int multi_bin_resident(vp_ctx* P)
     const bool plan = M->need_plan;
     const int rc = run_all(M, [&](Kid& k) -> int {
         vp_ctx* c = k.c;
+        (void)hipSetDevice(k.device);
+        VP_VOTE(kid_wait(M, k, "vp_bin (previous frame's exchanges)"));       // the bin's host polls its totals: never behind a stuck exchange
         if (plan) {
-            (void)hipSetDevice(k.device);
             VP_VOTE(VP_OK);                                    // every local rank is here: the collective inside plan_slabs can complete
             int r = plan_slabs(M, k); if (r) return r;
         }
-        return vp_bin_resident(c);
+        // the bin itself exchanges nothing: its result is agreed on, so that a slab whose pair count overflows (VP_ERR_UNSUPPORTED) fails the
+        // call on every rank alike instead of aborting the context
+        VP_VOTE(vp_bin_resident(c));
+        return VP_OK;
     });
     if (!rc) { M->need_plan = false; P->binned = true; P->filled = false; }
     return rc;
@@ -670,8 +703,9 @@ int multi_fill(vp_ctx* P, const vp_fill_params* p)
     const int rc = run_all(M, [&](Kid& k) -> int {
         vp_ctx* c = k.c;
         (void)hipSetDevice(k.device);
-        int rc0 = VP_OK;
-        if (!c->have_frame || !c->binned) rc0 = vp_fail(c, VP_ERR_STATE, "vp_fill before vp_set_frame / vp_bin");
+        // (uploads of the fill's inputs synchronise the stream: bounded wait first; nothing to upload -> nothing blocks, the fill queues behind the bin)
+        int rc0 = (p->cubemap || p->light_depth_map) ? kid_wait(M, k, "vp_fill (previous frame's exchanges)") : VP_OK;
+        if (!rc0 && (!c->have_frame || !c->binned)) rc0 = vp_fail(c, VP_ERR_STATE, "vp_fill before vp_set_frame / vp_bin");
         if (!rc0) rc0 = api_stage_fill_inputs(c, p);
         if (!rc0) rc0 = api_ensure_bricks(c, k.rank != 0);          // (rank 0 needs no (density, ao) scratch: fused fill, below)
         VP_VOTE(rc0);
@@ -722,7 +756,9 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         vp_ctx* c = k.c;
         (void)hipSetDevice(k.device);
         RmConsts kc;
-        int rc0 = api_stage_raymarch(c, cam, rp, &kc);
+        // (a scene-depth upload from pageable memory blocks in the runtime: bounded wait first; without one the march queues behind the fill)
+        int rc0 = rp && rp->scene_depth ? kid_wait(M, k, "vp_raymarch (previous exchanges)") : VP_OK;
+        if (!rc0) rc0 = api_stage_raymarch(c, cam, rp, &kc);
         VP_VOTE(rc0);
         kc.partial = 1;
         const int zb = kc.zB;
@@ -806,8 +842,11 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
         if (k.rank == 0) {
             if (d_out) VP_HIP(hipMemcpyAsync(d_out, k.d_final, M->npix * 4 * sizeof(float), hipMemcpyDeviceToDevice, k.stream));
             if (host_out) {
-                VP_HIP(hipMemcpyAsync(host_out, k.d_final, M->npix * 4 * sizeof(float), hipMemcpyDeviceToHost, k.stream));
+                // the bounded wait comes BEFORE the copy: a device-to-host copy into pageable memory blocks inside the runtime until the stream
+                // has reached it -- for ever, if an exchange in front of it lost its peer (found with the checking RCCL stand-in, round 5: the
+                // copy used to be queued first and swallowed the stall the time-out was there to catch)
                 { const int rw = kid_wait(M, k, "image exchange"); if (rw) return rw; }
+                VP_HIP(hipMemcpyAsync(host_out, k.d_final, M->npix * 4 * sizeof(float), hipMemcpyDeviceToHost, k.stream));
                 return api_stream_sync(c);
             }
         }
@@ -820,12 +859,13 @@ int multi_raymarch(vp_ctx* P, const vp_camera* cam, const vp_raymarch_params* rp
 int multi_sync(vp_ctx* P)
 {
     vp_multi* M = P->multi;
-    return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_sync"); return rw ? rw : vp_sync(k.c); });
+    return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_sync"); return rw ? rw : vp_sync(k.c); }, false);
 }
 
 int multi_set_occluders(vp_ctx* P, const vp_obb* boxes, int32_t n)
 {
-    return run_all(P->multi, [&](Kid& k) -> int { return vp_set_occluders(k.c, boxes, n); });
+    vp_multi* M = P->multi;
+    return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_set_occluders (previous frame's exchanges)"); return rw ? rw : vp_set_occluders(k.c, boxes, n); }, false);
 }
 
 vp_ctx* multi_owner_of_slice(vp_ctx* P, int zz)
