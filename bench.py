@@ -56,7 +56,7 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f in ("fill.hip", "raymarch.hip", "bin.hip", "vpfx_internal.h"):      # the kernels (host-side files do not change a counter)
+        if f in ("fill.hip", "fill_kernels.h", "raymarch.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):   # the kernels (host-side files do not change a counter)
             h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--rm-groups", type=int, default=0, help="N > 1: groups of the ray-march saturation hand-off (1 = none, N = serial chain, 0 = library default)")
     ap.add_argument("--uniform-slabs", action="store_true", help="equal-thickness slabs instead of the work-balanced cut")
     ap.add_argument("--no-reference-frame", action="store_true", help="N > 1: do not render the 1-GPU frame on rank 0 for the shard check")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the untimed content variants after the timed region (float cube map, coloured ambient, +x view: `variants` in the JSON line)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -332,6 +334,54 @@ def main():
     dt = float(t.item())
     voxels, samples, occupied, pairs, bricks_sampled, samples_formula = [float(x) for x in counts.tolist()]
 
+    # The headline above is the friendliest content combination the reference's defaults allow (8-bit cube map that fits LDS, grey ambient,
+    # the benchmark view).  The same frame under the inspector settings / views that take the other code paths, 20 steps each AFTER the timed
+    # region (never part of `value`): float cube-map texels (k_fill on the global footprint table), a coloured ambientColor (VPR.cs:90,537:
+    # RGBA16F bricks instead of grey z-pair entries -- four loads per sample in the ray-march instead of two), the view from +x (brick rows run
+    # along grid x: the least coherent footprint loads).
+    variants = None
+    if N == 1 and not args.no_variants and args.config != "DEMO":
+        variants = {}
+
+        def run_variant(name, fill_first=None, fill_next=None, camera=None, note=""):
+            cam_v = camera if camera is not None else cam
+            f_first, f_next = fill_first or fp_first, fill_next or fp
+            eng.bin_resident(); eng.fill(f_first); eng.raymarch_device(cam_v, rp, image.data_ptr())
+            for _ in range(2):
+                eng.bin_resident(); eng.fill(f_next); eng.raymarch_device(cam_v, rp, image.data_ptr())
+            barrier()
+            tv = time.perf_counter()
+            kf, kr = [], []
+            for i in range(20):
+                eng.bin_resident(); eng.fill(f_next); eng.raymarch_device(cam_v, rp, image.data_ptr())
+                if i % 5 == 4:
+                    kf.append(eng.last_kernel_ms(1)); kr.append(eng.last_kernel_ms(2))
+            barrier()
+            ms = (time.perf_counter() - tv) / 20 * 1e3
+            sv = eng.stats()
+            variants[name] = {"fill_ms": float(np.mean(kf)), "raymarch_ms": float(np.mean(kr)), "ms_per_step": ms,
+                              "samples_per_step": int(sv["samples"]), "brick_format": "grey z-pair" if sv.get("brick_format", 0) == 1 else "RGBA16F",
+                              "value": (sv["voxels_filled"] + sv["samples"]) / (ms * 1e-3) / 1e6, "what": note}
+
+        if args.cubemap == "r8":
+            sc_f = S.make_scene(args.config, cubemap="f32")
+            if args.displacement_scale is not None:
+                sc_f.displacement_scale = float(args.displacement_scale)
+            f1 = sc_f.fill_params()
+            f2 = sc_f.fill_params(); f2.cubemap = None
+            run_variant("cubemap_f32", f1, f2, note="float cube-map texels: k_fill on the global footprint table instead of the LDS-resident k_fill_lds")
+        amb_first, amb_next = sc.fill_params(), sc.fill_params()
+        for q in (amb_first, amb_next):
+            q.ambient[0], q.ambient[1], q.ambient[2] = 0.25, 0.2, 0.15
+        amb_next.cubemap = None
+        run_variant("coloured_ambient", amb_first, amb_next, note="ambientColor (0.25, 0.2, 0.15): RGBA16F bricks, four footprint loads per sample")
+        D = 0.8 * sc.N[0] * sc.mv_scale
+        sc_x = S.make_scene(args.config, cubemap=args.cubemap)
+        sc_x.set_camera((D, 0.05 * D, 0.125 * D))
+        run_variant("view_plus_x", fp_first, fp, camera=sc_x.camera(), note="camera on the grid's +x axis (brick rows run along x)")
+        eng.bin_resident(); eng.fill(fp_first)                      # leave the context as the timed region did
+        barrier()
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         nv = sc.nv
@@ -441,6 +491,8 @@ def main():
                           "handoff_chain_front_to_back": info["chain"], "handoff_group_of_rank": info["group_of"]} if N > 1 else None),
             "roofline": dict(roofs[dom], stage=dom),
             "roofline_all": roofs,
+            # untimed content variants of the same frame (20 steps each after the timed region; see above) -- the cliffs next to the headline
+            "variants": variants,
         }
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_threads, demo_boxes)   # (one frame WITH bin + fill; DEMO refills every 2nd frame)
