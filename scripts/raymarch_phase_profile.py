@@ -18,10 +18,18 @@ try:
     from vpfx_amd import engine as E, scene as S
     name = sys.argv[2] if len(sys.argv) > 2 else "C3"
     cube = sys.argv[3] if len(sys.argv) > 3 else "r8"
-    sc = S.make_scene(name, cubemap=cube)
+    boxes = None
+    if name == "DEMO":
+        sc, _, boxes = S.make_demo_scene()
+        if cube == "r8":
+            sc.cubemap = S.make_cubemap_r8()
+    else:
+        sc = S.make_scene(name, cubemap=cube)
     lib = E.lib()
     lib.vpfx_rm_probe_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     e = E.Engine(sc.config())
+    if boxes:
+        e.set_occluders(boxes)
     e.set_frame(sc.light_to_world, sc.grid_center)
     e.bin(sc.particles, sc.layout, sc.psys_local_to_world)
     e.fill(sc.fill_params())
