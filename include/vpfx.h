@@ -480,7 +480,9 @@ typedef struct vp_emitter_config {
     float cone_radius;           /* radius of the cone's base disc                                            (0.5)   */
     float angular_velocity_deg;  /* degrees per second                        RotationModule scene:2587-2621 (4)     */
     int32_t max_particles;       /* live particles never exceed this          numParticlesEmitted            (60)    */
-    int32_t reserved[6];
+    int32_t reserved[6];         /* [0] = 1: prewarm -- the reference's system has `prewarm: 1` (scene:2269) and starts in steady state; vp_emitter_create
+                                    then simulates one lifetime in 1/30 s steps (the default config leaves it 0: callers that step the emitter
+                                    themselves for `lifetime` seconds, as bench.py --config DEMO does, get the same cloud).  Others 0.   */
 } vp_emitter_config;
 void vp_emitter_default_config(vp_emitter_config* cfg);        /* the demo scene's values (the numbers in parentheses above), seed 7 */
 int  vp_emitter_create(const vp_emitter_config* cfg, vp_emitter** out);
@@ -499,9 +501,9 @@ int  vp_read_bincounts(vp_ctx* ctx, int32_t* counts /* [Nz][Ny][Nx] */);
 int  vp_read_brick(vp_ctx* ctx, int32_t xx, int32_t yy, int32_t zz, uint16_t* half_rgba /* nv^3*4 */);
 int  vp_read_lightmap(vp_ctx* ctx, float* out /* [(Ny*nv)][(Nx*nv)] */);
 int  vp_get_stats(vp_ctx* ctx, vp_stats* out);
-/* Device time in milliseconds of the dominant kernel of a stage over its most recent launch,
- * measured with HIP events on the context's stream. stage: 0 bin, 1 fill (vp_fill / vp_fill_local), 2 raymarch,
- * 3 vp_fill_finish. */
+/* Device time in milliseconds of a stage over its most recent launch, measured with HIP events on the context's stream.  stage: 0 bin,
+ * 1 fill (vp_fill / vp_fill_local), 2 raymarch -- since round 4 from in front of the frame preparation (k_rm_prepare: per-cell records, draw-order
+ * ranks, tile costs; + the dispatch-order sort) to the end of the march, i.e. the whole stage, not the march kernel alone --, 3 vp_fill_finish. */
 int  vp_last_kernel_ms(vp_ctx* ctx, int32_t stage, float* ms);
 
 #ifdef __cplusplus

@@ -54,6 +54,31 @@ def test_rate_cap_lifetime_and_cone():
     assert lateral[old].std() > 0.05                           # a cone, not a line
 
 
+def test_prewarm_starts_in_steady_state_like_the_reference_scene():
+    """scene:2269 `prewarm: 1`: the system is in steady state at the first frame.  vp_emitter_config.reserved[0] = 1 simulates one lifetime in
+    1/30 s steps inside vp_emitter_create: the same cloud as stepping an un-prewarmed emitter by hand; any other value is refused."""
+    L = E.lib()
+    L.vp_emitter_create.argtypes = [C.c_void_p, C.c_void_p]
+    cfg = default_cfg()
+    cfg.seed = 21
+    cfg.reserved[0] = 1
+    h = C.c_void_p()
+    assert L.vp_emitter_create(C.byref(cfg), C.byref(h)) == 0
+    n = L.vp_emitter_count(h)
+    assert 55 <= n <= 60                                       # rate x lifetime, capped by max_particles
+    by_hand = S.DemoEmitter(seed=21)
+    for _ in range(180):
+        by_hand.step(1.0 / 30.0)
+    ref = by_hand.particles()
+    got = np.zeros(n, dtype=S.PARTICLE_DTYPE)
+    lay = S.particle_layout(False)
+    assert L.vp_emitter_write_particles(h, got.ctypes.data_as(C.c_void_p), n, C.byref(lay)) == n == len(ref)
+    assert got.tobytes() == ref.tobytes()
+    L.vp_emitter_destroy(h)
+    cfg.reserved[0] = 7
+    assert L.vp_emitter_create(C.byref(cfg), C.byref(h)) == abi.VP_ERR_BAD_ARG
+
+
 def _pcg32_stream(seed):
     """PCG32 (XSH-RR 64/32) with the emitter's fixed stream constant: restated here, independent of the library."""
     M, inc, mask = 6364136223846793005, ((0xda3e39cb94b95bdb << 1) | 1) & (2**64 - 1), 2**64 - 1

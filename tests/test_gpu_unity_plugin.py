@@ -136,7 +136,19 @@ def test_render_target_shared_through_an_exported_fd(tmp_path):
     got = np.zeros((sc.height, sc.width, 4), dtype=np.float32)
     assert P.producer_read(view, offset, got.ctypes.data_as(C.c_void_p), got.nbytes) == 0
     assert np.array_equal(got, ref)                                  # the "texture" holds the frame, written by the ray-march itself
-    assert L.vp_unity_clear_slot(slot) == 0                          # drops the import; a late event is a no-op
+    # a plain device / host output registered AFTER an fd import replaces it (the import is released, not leaked) and survives:
+    # the next event writes the new host buffer, the shared memory keeps the previous frame
+    host = np.zeros((sc.height, sc.width, 4), dtype=np.float32)
+    L.vp_unity_register_output.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+    assert L.vp_unity_register_output(slot, None, host.ctypes.data_as(C.c_void_p)) == 0
+    sc2 = S.make_scene("C1", cubemap="r8")
+    sc2.set_camera((2.0, 1.0, -9.0))
+    frame2 = _desc(sc2, eng, 0, particles)
+    assert L.vp_unity_set_frame_desc(slot, C.byref(frame2)) == 0
+    _issue_plugin_event(L.vp_unity_render_event_func(), slot)
+    assert L.vp_unity_last_status(slot, None) == 0, L.vp_last_error(eng.h)
+    assert np.array_equal(host, direct.raymarch(sc2.camera(), sc2.raymarch_params()))
+    assert L.vp_unity_clear_slot(slot) == 0                          # a late event is a no-op
     _issue_plugin_event(L.vp_unity_render_event_func(), slot)
     assert L.vp_unity_last_status(slot, None) == abi.VP_ERR_STATE
     L.UnityPluginUnload()

@@ -90,6 +90,12 @@ VP_EMIT_API int vp_emitter_create(const vp_emitter_config* cfg, vp_emitter** out
     pcg32(e);
     e->state += cfg->seed;
     pcg32(e);
+    // prewarm (the reference's system has `prewarm: 1`, scene:2269: it starts in steady state, ~rate x lifetime particles alive): simulate one
+    // lifetime in 1/30 s steps before the first frame
+    if (cfg->reserved[0] == 1) {
+        const int steps = (int)std::ceil((double)cfg->lifetime * 30.0);
+        for (int i = 0; i < steps; ++i) { const int rc = vp_emitter_step(e, 1.0f / 30.0f); if (rc < 0) { delete e; return rc; } }
+    } else if (cfg->reserved[0] != 0) { delete e; return VP_ERR_BAD_ARG; }
     *out = e;
     return VP_OK;
 }

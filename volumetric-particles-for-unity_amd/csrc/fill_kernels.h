@@ -755,7 +755,9 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
         for (unsigned spins = 0; (unsigned)(bw >> 32) != blk + 1u; ++spins) {
             // a tag beyond the awaited one would mean the ring lapped a wave that sat RING x CLAIM tickets between two instructions: report, never mis-assign
             // (the bound is the ring's own: the chain test hook shortens ch.spin_limit to a few polls)
-            if ((unsigned)(bw >> 32) > blk + 1u || spins > VPFX_CHAIN_SPIN_LIMIT) { *ch.error = 1; bw = ((unsigned long long)(blk + 1u) << 32) | 0x7fffffffull; break; }
+            // (base = nitems: every slot of the block then fails the `item >= nitems` test below and the wave leaves; 0x7fffffff + slot overflowed
+            //  into a negative unit index for slot > 0 -- ADVICE r4)
+            if ((unsigned)(bw >> 32) > blk + 1u || spins > VPFX_CHAIN_SPIN_LIMIT) { *ch.error = 1; bw = ((unsigned long long)(blk + 1u) << 32) | (unsigned long long)(unsigned)nitems; break; }
             __builtin_amdgcn_s_sleep(1);
             bw = __hip_atomic_load(&s_block[blk & (VPFX_FILL_CLAIM_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }

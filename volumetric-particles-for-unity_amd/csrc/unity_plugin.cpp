@@ -27,6 +27,7 @@ struct Slot {
     bool running = false;         // an event of this slot is executing (vp_unity_clear_slot waits for it)
     hipExternalMemory_t ext = nullptr;   // vp_unity_register_output_fd: the imported allocation d_out points into
     int ext_device = 0;
+    void* ext_ptr = nullptr;             // the mapping of that import (d_out while the import is the slot's device output)
 };
 std::mutex g_m;
 std::condition_variable g_cv;
@@ -41,7 +42,8 @@ void release_external(Slot& s)
     (void)hipSetDevice(s.ext_device);
     (void)hipDeviceSynchronize();                     // nothing of ours may still be writing the shared memory
     (void)hipDestroyExternalMemory(s.ext);
-    s.ext = nullptr; s.d_out = nullptr;
+    if (s.d_out == s.ext_ptr) s.d_out = nullptr;      // only the output that pointed INTO the import dies with it (a device buffer
+    s.ext = nullptr; s.ext_ptr = nullptr;             // registered later must survive the release of an older import)
 }
 
 void on_render_event(int slot)
@@ -97,7 +99,8 @@ VP_EXPORT void UnityPluginLoad(void* unity_interfaces)
 
 VP_EXPORT void UnityPluginUnload(void)
 {
-    std::lock_guard<std::mutex> lk(g_m);
+    std::unique_lock<std::mutex> lk(g_m);
+    g_cv.wait(lk, [&] { for (const Slot& s : g_slots) if (s.running) return false; return true; });      // an event that is executing keeps its import
     for (Slot& s : g_slots) { release_external(s); s = Slot{}; }
     g_unity_interfaces = nullptr;
     g_loaded = false;
@@ -117,7 +120,9 @@ VP_EXPORT int vp_unity_set_frame_desc(int32_t slot, const vp_unity_frame* frame)
 VP_EXPORT int vp_unity_register_output(int32_t slot, void* d_rgba_out, float* h_rgba_out)
 {
     if (slot < 0 || slot >= VP_UNITY_MAX_SLOTS) return VP_ERR_BAD_ARG;
-    std::lock_guard<std::mutex> lk(g_m);
+    std::unique_lock<std::mutex> lk(g_m);
+    g_cv.wait(lk, [&] { return !g_slots[slot].running; });      // an event of the slot that is executing right now keeps its outputs
+    release_external(g_slots[slot]);                             // a previous vp_unity_register_output_fd import is replaced, not leaked
     g_slots[slot].d_out = d_rgba_out;
     g_slots[slot].h_out = h_rgba_out;
     return VP_OK;
@@ -155,7 +160,7 @@ VP_EXPORT int vp_unity_register_output_fd(int32_t slot, vp_ctx* ctx, int32_t fd,
     std::unique_lock<std::mutex> lk(g_m);
     g_cv.wait(lk, [&] { return !g_slots[slot].running; });
     release_external(g_slots[slot]);
-    g_slots[slot].ext = ext; g_slots[slot].ext_device = c->device;
+    g_slots[slot].ext = ext; g_slots[slot].ext_device = c->device; g_slots[slot].ext_ptr = dptr;
     g_slots[slot].d_out = dptr;
     return VP_OK;
 }
