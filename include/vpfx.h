@@ -335,9 +335,10 @@ int  vp_rebalance(vp_ctx* ctx);
  * (any transport: MPI, a TCP store, a file) and pass them in vp_config.rccl_unique_id. */
 int  vp_rccl_unique_id(uint8_t out[128]);
 /* The slab cut itself (host-only, no GPU needed): fill_ms[z] (the fill's local pass), rm_ms[z] = estimated milliseconds per light-axis
- * slice.  The frame waits for the slowest slab in the local pass (it ends in the all-gather of the transmittance maps) and then for the
- * slowest slab's finish pass (0.42 x its local pass; not the slab nearest the light, whose fill is fused) + ray-march (per hand-off group
- * when rm_groups > 1).  cuts_out[world + 1]. */
+ * slice.  The slabs behind the first wait for the slowest slab's local pass (it ends in the all-gather of the transmittance maps) and then run
+ * their finish pass (0.42 x the local pass) + ray-march (per hand-off group when rm_groups > 1); the slab nearest the light runs the fused fill,
+ * needs nobody's light and marches as soon as its own fill is done (the all-gather runs on the library's exchange stream beside it): the frame
+ * is the later of the two paths, and the cut minimises that.  cuts_out[world + 1]. */
 int  vp_plan_slabs(int32_t nz, int32_t world, const double* fill_ms, const double* rm_ms, int32_t rm_groups, int32_t* cuts_out);
 /* Front-to-back compositing order of the slabs for a given zBoundary (VPR.cs:652-711 at slab granularity) and the blend plan of their
  * partial images: chain_out[world] = ranks front to back (the slab straddling zBoundary first, then the phase-A slabs zz descending, then

@@ -8,7 +8,11 @@ For every (N, hand-off groups):
      the device and stretch each other), with the same cut, the same kernels and the real hand-off maps of the slabs in front
      (vp_raymarch_partial_handoff_device), front to back along the chain;
   3. the per-rank kernel times are combined as the pipeline does:
-        t_N = max_r(bin_r + fill_local_r) + t(tau all-gather) + max_r(finish_r + raymarch_r) + t(image exchange) + t(blend)      [one group]
+        t_N = max( bin_0 + fill_0 + raymarch_0 ,  max_r(bin_r + fill_local_r) + t(tau all-gather) + max_{r>0}(finish_r + raymarch_r) )
+              + t(image exchange) + t(blend)                                                                                     [one group]
+        (round 5: the all-gather of the transmittance maps runs on the library's exchange stream; slab 0 -- fused fill, nobody's light needed --
+         marches as soon as its own fill is done; round 4's serial schedule, max_r(bin + fill_local) + t_tau + max_r(finish + raymarch), is
+         printed beside it)
         t_N = max_r(bin_r + fill_local_r) + t(tau all-gather) + max_r(finish_r)
             + sum over hand-off groups g of max_{r in g}(raymarch_r) + (groups - 1) * t(hand-off hop) + t(image exchange) + t(blend)
      (slab 0, nearest the light, runs the fused fill: fill_local_0 = its fused kernel, finish_0 = 0)
@@ -104,18 +108,24 @@ for world in (2, 4, 7, 8):                # (7: the slab cut of the alternative 
         t_blend = 0.02e-3
         G = max(group_of) + 1
         rm_groups = [max(rows[r]["rm"] for r in chain if group_of[r] == g) for g in range(G)]
-        if G == 1:      # after the tau all-gather every slab runs its finish pass (not slab 0) and its ray-march back to back; the image exchange waits for the slowest
-            after = max(x["finish"] + x["rm"] for x in rows.values())
+        fill_max = max(x["bin"] + x["fill_local"] for x in rows.values())
+        if G == 1:      # after the tau all-gather every slab but slab 0 runs its finish pass and its ray-march back to back; slab 0 marches right after its fused fill
+            after = max([x["finish"] + x["rm"] for r, x in rows.items() if r != 0] or [0.0])
+            path0 = rows[0]["bin"] + rows[0]["fill_local"] + rows[0]["rm"]
+            t = max(path0 * 1e-3, (fill_max + after) * 1e-3 + t_tau) + t_img + t_blend
+            t_serial = (fill_max + max(x["finish"] + x["rm"] for x in rows.values())) * 1e-3 + t_tau + t_img + t_blend      # round 4's schedule
         else:
             after = max(x["finish"] for x in rows.values()) + sum(rm_groups)
-        t = (max(x["bin"] + x["fill_local"] for x in rows.values()) + after) * 1e-3 + t_tau + (G - 1) * t_hop + t_img + t_blend
+            t = (fill_max + after) * 1e-3 + t_tau + (G - 1) * t_hop + t_img + t_blend
+            t_serial = t
         key = f"{world}gpu_{groups}groups"
         out["predictions"][key] = {
             "world": world, "rm_groups": groups, "slab_cuts": cuts, "chain": chain, "group_of": group_of, "per_rank": [rows[r] for r in range(world)],
             "max_abs_rgba_diff_vs_1gpu_frame": err, "t_allgather_tau_ms": t_tau * 1e3, "t_handoff_hop_ms": t_hop * 1e3, "t_image_exchange_ms": t_img * 1e3,
-            "raymarch_ms_per_group": rm_groups, "predicted_ms_per_step": t * 1e3, "speedup_vs_1gpu": one_ms / (t * 1e3),
+            "raymarch_ms_per_group": rm_groups, "predicted_ms_per_step": t * 1e3, "predicted_ms_per_step_serial_schedule_r4": t_serial * 1e3,
+            "speedup_vs_1gpu": one_ms / (t * 1e3),
             "samples_executed_all_ranks": sum(x["samples"] for x in rows.values())}
-        print(f"N={world} groups={groups}: predicted {t * 1e3:.2f} ms/step ({one_ms / (t * 1e3):.2f}x); cut {cuts}; "
+        print(f"N={world} groups={groups}: predicted {t * 1e3:.2f} ms/step ({one_ms / (t * 1e3):.2f}x; serial schedule {t_serial * 1e3:.2f}); cut {cuts}; "
               f"max bin+fill_local {max(x['bin'] + x['fill_local'] for x in rows.values()):.2f} finish {max(x['finish'] for x in rows.values()):.2f} max finish+rm {max(x['finish'] + x['rm'] for x in rows.values()):.2f} "
               f"rm per group {[round(x, 3) for x in rm_groups]} (max single {max(x['rm'] for x in rows.values()):.3f}); exchanges {1e3 * (t_tau + (G - 1) * t_hop + t_img):.2f}; "
               f"samples {sum(x['samples'] for x in rows.values()) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M; fan-out image err {err:.1e}", flush=True)
@@ -148,7 +158,7 @@ for side in (0, 1):
 e.close()
 rows7 = p7["per_rank"]
 fill_max = max(x["bin"] + x["fill_local"] for x in rows7)
-after7 = max([x["finish"] + x["rm"] for x in rows7[1:]] + [h["rm"] for h in halves])
+after7 = max([x["finish"] + x["rm"] for x in rows7[1:]] + [h["rm"] for h in halves])      # (serial schedule: a plan that replicates the front slab has no decoupled first rank)
 piece8 = npix * 16 / 8
 t_alt = (fill_max + after7) * 1e-3 + (LAT + lm_bytes / LINK1) + 2 * (LAT + piece8 / LINK1) + 0.02e-3
 base8 = out["predictions"]["8gpu_1groups"]["predicted_ms_per_step"]
@@ -160,5 +170,5 @@ print(f"ALTERNATIVE at 8 GPUs -- front slab {cuts7[:2]} filled on two ranks, scr
       f"{halves[0]['rm']:.3f} / {halves[1]['rm']:.3f} ms (whole: {rows7[0]['rm']:.3f}), max bin+fill_local {fill_max:.2f} (8 slabs: "
       f"{max(x['bin'] + x['fill_local'] for x in out['predictions']['8gpu_1groups']['per_rank']):.2f}), max after the all-gather {after7:.2f}: "
       f"predicted {t_alt * 1e3:.2f} ms/step vs {base8:.2f} for eight slabs -> {'BEATS' if t_alt * 1e3 < base8 else 'does NOT beat'} it", flush=True)
-os.makedirs("gpurun_out/r4_scaling", exist_ok=True)
-json.dump(out, open(f"gpurun_out/r4_scaling/scaling_model_{name}_{cube}.json", "w"), indent=1)
+os.makedirs("gpurun_out/r5_scaling", exist_ok=True)
+json.dump(out, open(f"gpurun_out/r5_scaling/scaling_model_{name}_{cube}.json", "w"), indent=1)

@@ -145,8 +145,10 @@ def test_library_slab_planner_is_valid_and_optimal():
         R = rng.random(nz) * 2 if kind != 2 else np.concatenate([rng.random(2) * 9, np.zeros(nz - 2)])   # ray-march work piled at the front
         b = E.plan_slabs(nz, world, F, R, 1)
         assert b[0][0] == 0 and b[-1][1] == nz and all(b0 < b1 for b0, b1 in b) and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
-        # local pass (ends in a collective) + the slowest of [finish pass (not the fused first slab) + ray-march]
-        obj = lambda bb: max(F[a:c].sum() for a, c in bb) + max((0.42 * F[a:c].sum() if i else 0.0) + R[a:c].sum() for i, (a, c) in enumerate(bb))
+        # the slabs behind the first: slowest local pass (it ends in the all-gather) + the slowest of [finish pass + ray-march]; the fused first
+        # slab needs nobody's light and marches as soon as ITS fill is done (the all-gather runs beside its compute stream, round 5)
+        obj = lambda bb: max(F[bb[0][0]:bb[0][1]].sum() + R[bb[0][0]:bb[0][1]].sum(),
+                             max(F[a:c].sum() for a, c in bb) + max(0.42 * F[a:c].sum() + R[a:c].sum() for a, c in bb[1:]))
         best = min(obj(list(zip((0,) + c, c + (nz,)))) for c in itertools.combinations(range(1, nz), world - 1))
         assert abs(obj(b) - best) <= 1e-9                                              # exact optimum of the two-stage frame model
         # with hand-off groups the cut stays valid and is never worse than the fill-only cut under that model

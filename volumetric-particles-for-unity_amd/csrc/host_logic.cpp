@@ -250,44 +250,55 @@ void min_max_partition(int nz, int world, const std::vector<double>& w, int* cut
 // The finish pass of the split fill (stream (density, ao) back, store the bricks) as a share of the slab's local pass: 0.75 / 1.72, 0.38 / 0.94,
 // 0.29 / 0.60 ms at 2 / 4 / 8 slabs of C3 (profiles/r03_scaling_model_C3_r8.txt).
 #define VPFX_FINISH_SHARE 0.42
-// Exact optimum of  max_r F_r + max_r (C F_r [r > 0] + R_r)  over contiguous partitions into `world` slabs of >= 1 slice: F = per-slice cost
-// of the fill's local pass, which ends in a collective (every slab waits for the slowest); after it a slab runs its finish pass (C F; not the
-// first slab, whose fill is fused) and its ray-march (R) back to back, and the image exchange waits for the slowest of THOSE.  For every
-// candidate bound B on the first maximum (all interval sums of F), a min-max DP of the second term over the partitions whose slabs all keep
-// F <= B; the best B wins.  nz^2 / 2 bounds x world x nz^2 steps: ~4 M at nz = 32.
+// Exact optimum of the one-group frame model over contiguous partitions into `world` slabs of >= 1 slice:
+//     frame = max( F_0 + R_0 ,  max_r F_r  +  max_{r > 0} (C F_r + R_r) )
+// F = per-slice cost of the fill's local pass, R = of the ray-march.  The local passes end in the all-gather of the transmittance maps, which
+// completes when the slowest slab has filled (max_r F_r); after it every slab BUT THE FIRST runs its finish pass (C F) and its ray-march (R)
+// back to back, and the image exchange waits for the slowest of those.  The first slab's fill is fused and needs nobody's light: since round 5
+// the all-gather runs beside its compute stream (multi.cpp: exchange stream), so its march starts when its own fill ends -- its path is
+// F_0 + R_0, whatever the others do.  For every candidate bound B on max_r F_r (all interval sums of F): a min-max DP over the partitions of
+// the slices behind the first cut into world - 1 slabs that keep F <= B, then the best first cut; the best B wins.  nz^2 / 2 bounds x world x nz^2
+// steps: ~4 M at nz = 32.
 double two_maxima_partition(int nz, int world, const std::vector<double>& F, const std::vector<double>& R, double C, int* cuts)
 {
     std::vector<double> pf(nz + 1, 0.0), pr(nz + 1, 0.0);
     for (int z = 0; z < nz; ++z) { pf[z + 1] = pf[z] + std::max(F[z], 0.0); pr[z + 1] = pr[z] + std::max(R[z], 0.0); }
+    const double INF = 1e300;
+    if (world == 1) { cuts[0] = 0; cuts[1] = nz; return pf[nz] + pr[nz]; }
     std::vector<double> bounds;
     for (int y = 0; y < nz; ++y)
         for (int z = y + 1; z <= nz; ++z) bounds.push_back(pf[z] - pf[y]);
     std::sort(bounds.begin(), bounds.end());
     bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
-    const double INF = 1e300;
     double best = INF;
-    std::vector<std::vector<double>> dp(world + 1, std::vector<double>(nz + 1));
-    std::vector<std::vector<int>> arg(world + 1, std::vector<int>(nz + 1));
-    std::vector<int> cand(world + 1);
+    // g[k][y] = the smallest achievable max (C F + R) over the partitions of slices [y, nz) into k slabs with F <= B each; arg = the first cut
+    std::vector<std::vector<double>> g(world, std::vector<double>(nz + 1));
+    std::vector<std::vector<int>> arg(world, std::vector<int>(nz + 1));
     for (double B : bounds) {
         if (B >= best) break;                                // bounds ascend: no later one can win
-        for (auto& row : dp) std::fill(row.begin(), row.end(), INF);
-        dp[0][0] = 0.0;
-        for (int k = 1; k <= world; ++k)
-            for (int z = k; z <= nz - (world - k); ++z)
-                for (int y = k - 1; y < z; ++y) {
-                    if (dp[k - 1][y] >= INF || pf[z] - pf[y] > B) continue;
-                    const double v = std::max(dp[k - 1][y], (pr[z] - pr[y]) + (k > 1 ? C * (pf[z] - pf[y]) : 0.0));   // k == 1: the fused first slab has no finish pass
-                    if (v < dp[k][z]) { dp[k][z] = v; arg[k][z] = y; }
+        for (auto& row : g) std::fill(row.begin(), row.end(), INF);
+        g[0][nz] = 0.0;
+        for (int k = 1; k <= world - 1; ++k)
+            for (int y = nz - k; y >= world - 1 - k + 1; --y)       // [y, nz) holds k slabs; world - 1 - k slabs + the first one still fit in front
+                for (int z = y + 1; z <= nz - (k - 1); ++z) {
+                    if (g[k - 1][z] >= INF || pf[z] - pf[y] > B) continue;
+                    const double v = std::max(g[k - 1][z], (pr[z] - pr[y]) + C * (pf[z] - pf[y]));
+                    if (v < g[k][y]) { g[k][y] = v; arg[k][y] = z; }
                 }
-        if (dp[world][nz] >= INF) continue;
-        int z = nz;
-        cand[world] = nz;
-        for (int k = world; k >= 1; --k) { z = arg[k][z]; cand[k - 1] = z; }
-        double fmax = 0.0;
-        for (int r = 0; r < world; ++r) fmax = std::max(fmax, pf[cand[r + 1]] - pf[cand[r]]);
-        const double t = fmax + dp[world][nz];
-        if (t < best - 1e-12) { best = t; for (int i = 0; i <= world; ++i) cuts[i] = cand[i]; }
+        for (int z1 = 1; z1 <= nz - (world - 1); ++z1) {
+            if (pf[z1] > B || g[world - 1][z1] >= INF) continue;
+            // (the bound must be attained or undercut by the real maximum: evaluate the partition itself)
+            double fmax = pf[z1];
+            int y = z1;
+            for (int k = world - 1; k >= 1; --k) { const int z = arg[k][y]; fmax = std::max(fmax, pf[z] - pf[y]); y = z; }
+            const double t = std::max(pf[z1] + pr[z1], fmax + g[world - 1][z1]);
+            if (t < best - 1e-12) {
+                best = t;
+                cuts[0] = 0; cuts[1] = z1;
+                y = z1;
+                for (int k = world - 1, i = 2; k >= 1; --k, ++i) { y = arg[k][y]; cuts[i] = y; }
+            }
+        }
     }
     return best;
 }
@@ -331,7 +342,7 @@ void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms
             for (int z = 0; z < nz; ++z) w[z] = a < 0.0 ? Rv[z] : Fv[z] + a * Rv[z];
             min_max_partition(nz, world, w, cand.data());
         }
-        double fmax = 0.0, finmax = 0.0, onemax = 0.0;
+        double fmax = 0.0, finmax = 0.0, onemax = 0.0, first_path = 0.0;
         std::vector<double> gmax(world, 0.0);
         for (int r = 0; r < world; ++r) {
             double f = 0.0, m = 0.0;
@@ -339,11 +350,11 @@ void hl_plan_slabs(int nz, int world, const double* fill_ms, const double* rm_ms
             const double fin = r > 0 ? VPFX_FINISH_SHARE * f : 0.0;          // the fused first slab has no finish pass
             fmax = std::max(fmax, f);
             finmax = std::max(finmax, fin);
-            onemax = std::max(onemax, fin + m);
+            if (r == 0) first_path = f + m; else onemax = std::max(onemax, fin + m);
             gmax[gp[r]] = std::max(gmax[gp[r]], m);
         }
         double t = fmax;
-        if (gp[world - 1] == 0) t += onemax;                          // one group: finish and ray-march of a slab run back to back
+        if (gp[world - 1] == 0) t = std::max(first_path, fmax + onemax);   // one group: finish and ray-march of a slab run back to back; the fused first slab marches as soon as ITS fill is done
         else { t += finmax; for (double g : gmax) t += g; }           // chained groups (conservative: every finish before the first group)
         if (!have || t < best_t - 1e-12) { best_t = t; have = true; for (int i = 0; i <= world; ++i) cuts[i] = cand[i]; }
     }

@@ -111,6 +111,14 @@ struct Kid {
     vp_ctx* c = nullptr;              // the slab context
     int rank = 0, device = 0, index = 0;
     hipStream_t stream = nullptr;
+    // Exchange stream (round 5): the all-gather of the slab transmittance maps runs HERE, beside the rank's compute stream.  Only the finish pass
+    // of a rank > 0 waits for it; rank 0 -- whose fused fill needs nobody's light and whose slab usually holds most of the ray-march -- goes
+    // straight from its fill into its march.  One communicator, two streams: the rank's compute stream waits for ev_tau before it issues its
+    // next operation on the communicator (comm_fence), so operations of the communicator never run side by side and every rank still issues them
+    // in the same order (tau all-gather, then hand-off, then image exchange).
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_local = nullptr, ev_tau = nullptr;      // local fill pass done (compute stream) / transmittance maps gathered (exchange stream)
+    bool tau_pending = false;                             // ev_tau recorded and not yet waited for by the compute stream
     ncclComm_t comm = nullptr;
     // Guards `comm` against the one cross-thread access there is: multi_abort (any thread) takes the communicator away and ncclCommAbort()s it
     // -- which frees it -- while this rank's own thread may be about to hand it to ncclSend / ncclRecv / ncclAllGather / ncclCommGetAsyncError.
@@ -213,7 +221,8 @@ int kid_wait(vp_multi* M, Kid& k, const char* what)
     vp_ctx* c = k.c;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; ++spin) {
-        const hipError_t e = hipStreamQuery(k.stream);
+        hipError_t e = hipStreamQuery(k.stream);
+        if (e == hipSuccess && k.xstream) e = hipStreamQuery(k.xstream);       // (an all-gather still running beside an idle compute stream)
         if (e == hipSuccess) return M->aborted.load() ? aborted_fail(M, c) : VP_OK;
         if (e != hipErrorNotReady) { (void)hipGetLastError(); multi_abort(M, k.rank, std::string(what) + ": " + hipGetErrorString(e)); return aborted_fail(M, c); }
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -314,17 +323,27 @@ int vote(vp_multi* M, int rc)
 // Exchanges.  RCCL: grouped ncclSend / ncclRecv and ncclAllGather on the rank's communicator and stream.  Loopback (test hook):
 // receiver posts its buffer, sender copies device to device on ITS stream and records an event, receiver's stream waits for the event.
 // ---------------------------------------------------------------------------------------------------------------------------------
-int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
+// Before the compute stream issues an operation on the communicator: the all-gather the exchange stream may still be running has to be over
+// (one operation of a communicator at a time, in the order every rank issues them).
+int comm_fence(Kid& k)
+{
+    vp_ctx* c = k.c;
+    if (k.tau_pending) { VP_HIP(hipStreamWaitEvent(k.stream, k.ev_tau, 0)); k.tau_pending = false; }
+    return VP_OK;
+}
+
+int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops, hipStream_t stream = nullptr)
 {
     vp_ctx* c = k.c;
     if (ops.empty()) return VP_OK;
+    if (!stream) { stream = k.stream; const int rf = comm_fence(k); if (rf) return rf; }
     if (M->use_rccl) {
         Rccl& R = rccl();
         std::lock_guard<std::timed_mutex> lk(*k.comm_m);
         if (!k.comm) return aborted_fail(M, c);             // taken away by multi_abort
         VP_NCCL(R.GroupStart());
         for (const P2P& o : ops) {
-            const ncclResult_t r = o.send ? R.Send(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, k.stream) : R.Recv(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, k.stream);
+            const ncclResult_t r = o.send ? R.Send(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, stream) : R.Recv(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, stream);
             if (r != ncclSuccess) { (void)R.GroupEnd(); return vp_fail(c, VP_ERR_RCCL, "ncclSend/ncclRecv failed: %s", R.GetErrorString(r)); }
         }
         VP_NCCL(R.GroupEnd());
@@ -363,8 +382,8 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
             if (k.drop_next_send) { k.drop_next_send = false; continue; }      // TEST HOOK: this rank silently leaves the exchange
             hipEvent_t ev = nullptr;
             VP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            VP_HIP(hipMemcpyAsync(dst, o.ptr, o.bytes, hipMemcpyDefault, k.stream));
-            VP_HIP(hipEventRecord(ev, k.stream));
+            VP_HIP(hipMemcpyAsync(dst, o.ptr, o.bytes, hipMemcpyDefault, stream));
+            VP_HIP(hipEventRecord(ev, stream));
             {
                 std::lock_guard<std::mutex> lk(M->mm);
                 Mail& ml = M->box[key];
@@ -386,20 +405,21 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops)
             ev = M->box[key].ev;
             M->box.erase(key);
         }
-        VP_HIP(hipStreamWaitEvent(k.stream, ev, 0));
+        VP_HIP(hipStreamWaitEvent(stream, ev, 0));
         VP_HIP(hipEventDestroy(ev));                     // released once the wait has consumed it
     }
     return VP_OK;
 }
 
 // all-gather IN PLACE: rank r's block already sits at buf + r * count
-int all_gather_inplace(vp_multi* M, Kid& k, float* buf, size_t count)
+int all_gather_inplace(vp_multi* M, Kid& k, float* buf, size_t count, hipStream_t stream = nullptr)
 {
     vp_ctx* c = k.c;
+    if (!stream) { stream = k.stream; const int rf = comm_fence(k); if (rf) return rf; }
     if (M->use_rccl) {
         std::lock_guard<std::timed_mutex> lk(*k.comm_m);
         if (!k.comm) return aborted_fail(M, c);             // taken away by multi_abort
-        VP_NCCL(rccl().AllGather(buf + (size_t)k.rank * count, buf, count, ncclFloat, k.comm, k.stream));
+        VP_NCCL(rccl().AllGather(buf + (size_t)k.rank * count, buf, count, ncclFloat, k.comm, stream));
         return VP_OK;
     }
     std::vector<P2P> ops;
@@ -410,7 +430,7 @@ int all_gather_inplace(vp_multi* M, Kid& k, float* buf, size_t count)
             ops.push_back(P2P{false, r, buf + (size_t)r * count, count * sizeof(float)});
             ops.push_back(P2P{true, r, buf + (size_t)k.rank * count, count * sizeof(float)});
         }
-    return p2p_batch(M, k, ops);
+    return p2p_batch(M, k, ops, stream);
 }
 
 int copy_on_stream(Kid& k, void* dst, const void* src, size_t bytes)
@@ -432,12 +452,22 @@ void free_kid(Kid& k)
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         (void)hipGetLastError();
     }
+    if (k.xstream) {
+        const auto t1 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(k.xstream) == hipErrorNotReady &&
+               std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() < 5000)
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        (void)hipGetLastError();
+    }
     if (k.comm && rccl().so) (void)rccl().CommDestroy(k.comm);
     void* bufs[] = {k.d_tau_all, k.d_img[0], k.d_img[1], k.d_tmaps, k.d_tout[0], k.d_tout[1], k.d_pieces, k.d_piece_out, k.d_final, k.d_xfer};
     for (void* p : bufs) if (p) (void)hipFree(p);
     for (auto& e : k.ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
     if (k.c) { k.c->stream = nullptr; vp_destroy_single(k.c); }
     if (k.stream) (void)hipStreamDestroy(k.stream);
+    if (k.xstream) (void)hipStreamDestroy(k.xstream);
+    if (k.ev_local) (void)hipEventDestroy(k.ev_local);
+    if (k.ev_tau) (void)hipEventDestroy(k.ev_tau);
     k = Kid{};
 }
 
@@ -577,7 +607,9 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
         one.slab_z0 = M->cuts[k.rank]; one.slab_z1 = M->cuts[k.rank + 1];
         int rc = vp_create_single(&one, &k.c);
         if (rc) return fail(rc, "slab context");
-        if (hipSetDevice(k.device) != hipSuccess || hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess) return fail(VP_ERR_HIP, "hipStreamCreate");
+        if (hipSetDevice(k.device) != hipSuccess || hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&k.xstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&k.ev_local, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&k.ev_tau, hipEventDisableTiming) != hipSuccess) return fail(VP_ERR_HIP, "hipStreamCreate");
         k.c->stream = k.stream;
         const size_t img = M->pixpad * 4, plane = M->npix;
         const size_t pieces = gather_all ? (size_t)(world + 1) * M->pixpad * 4 : (size_t)(world + 1) * M->piece * 4;
@@ -715,6 +747,8 @@ int multi_fill(vp_ctx* P, const vp_fill_params* p)
         const bool fused = k.rank == 0;
         int r;
         c->filled = false;
+        // (the previous frame's all-gather read this rank's slot of d_tau_all on the exchange stream: over before the fill below rewrites it)
+        { const int rf = comm_fence(k); if (rf) return rf; }
         if (fused) {
             r = launch_fill(c, 0, nullptr, c->d_lightmap);
             if (!r && hipMemcpyAsync(k.d_tau_all, c->d_lightmap, M->lm * sizeof(float), hipMemcpyDeviceToDevice, k.stream) != hipSuccess)
@@ -726,11 +760,18 @@ int multi_fill(vp_ctx* P, const vp_fill_params* p)
             c->local_done = r == VP_OK;
         }
         VP_VOTE(r);                                             // a rank whose launch failed must not leave the others inside the all-gather
-        VP_HIP(hipEventRecord(k.ev[0][0], k.stream));
-        r = all_gather_inplace(M, k, k.d_tau_all, M->lm); if (r) return r;
-        VP_HIP(hipEventRecord(k.ev[0][1], k.stream));
+        // the all-gather runs on the exchange stream, after this rank's map is written ...
+        VP_HIP(hipEventRecord(k.ev_local, k.stream));
+        VP_HIP(hipStreamWaitEvent(k.xstream, k.ev_local, 0));
+        VP_HIP(hipEventRecord(k.ev[0][0], k.xstream));
+        r = all_gather_inplace(M, k, k.d_tau_all, M->lm, k.xstream); if (r) return r;
+        VP_HIP(hipEventRecord(k.ev[0][1], k.xstream));
+        VP_HIP(hipEventRecord(k.ev_tau, k.xstream));
         k.ev_valid[0] = true;
+        k.tau_pending = true;
         if (!fused) {
+            // ... and only the finish pass waits for it (rank 0's compute stream carries on: its next wait is in front of its next exchange)
+            { const int rf = comm_fence(k); if (rf) return rf; }
             // finish pass: T_in = tau[0] * ... * tau[rank - 1] formed inside the kernel, straight from the receive buffer
             c->finish_tau_all = k.d_tau_all;
             c->finish_n_before = k.rank;
