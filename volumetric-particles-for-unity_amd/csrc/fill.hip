@@ -38,9 +38,10 @@ k_build_cubequads(const T* __restrict__ cube, int S, float4* __restrict__ quads_
 }
 
 __global__ void __launch_bounds__(256)
-k_fill_value(float* __restrict__ d, size_t n, float v)
+k_fill_value(float* __restrict__ d, size_t n, float v, int* __restrict__ zero_word /* nullable */)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && zero_word) *zero_word = 0;
     if (i < n) d[i] = v;
 }
 
@@ -62,9 +63,9 @@ k_build_cube_u8(const uint8_t* __restrict__ cube, int S, int pitch, uint8_t* __r
 
 }  // namespace
 
-int launch_fill_value(vp_ctx* c, float* d, size_t n, float v)
+int launch_fill_value(vp_ctx* c, float* d, size_t n, float v, int* zero_word)
 {
-    hipLaunchKernelGGL(k_fill_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, n, v);
+    hipLaunchKernelGGL(k_fill_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, n, v, zero_word);
     VP_HIP(hipGetLastError());
     return VP_OK;
 }

@@ -890,14 +890,17 @@ int allow_big_lds(vp_ctx* c, K kernel, size_t bytes)
 
 // Host side of a chained launch: light map preset for the columns without an occupied metavoxel (the others are overwritten by their last
 // unit), a fresh tag range for the hand-off words.
+// (the work counter of the persistent kernels is reset by the same launch that presets the light map: one command in front of the fill
+//  instead of a kernel and a memset -- the reference scene's frame is 0.19 ms and every command costs 5-10 us of it)
 int chain_begin(vp_ctx* c, const FillPtrs& P, int mode, FillChain& ch)
 {
     const size_t lm = (size_t)c->g.Nx * c->g.nv * c->g.Ny * c->g.nv;
     if (mode == 0 && P.light_in) {
         if (P.light_in != P.light_out) VP_HIP(hipMemcpyAsync(P.light_out, P.light_in, lm * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     } else {
-        int rc = launch_fill_value(c, P.light_out, lm, 1.0f); if (rc) return rc;
+        int rc = launch_fill_value(c, P.light_out, lm, 1.0f, c->d_work_counter); if (rc) return rc;
     }
+    if (mode == 0 && P.light_in) VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     const uint32_t span = (uint32_t)c->g.Nz + 1u;
     if (c->chain_seq >= 0xffffffffu / span - 1u) {              // tags would wrap: start over with cleared words
         VP_HIP(hipMemsetAsync(c->d_chain, 0, lm * sizeof(unsigned long long), c->stream));
@@ -925,7 +928,6 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     const int nitems = c->h_meta.occupied * TPC;
     { int rc = chain_begin(c, P, MODE, ch); if (rc) return rc; }
     if (nitems == 0) return VP_OK;
-    VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     constexpr int WV = VPFX_FILL_LDS_WAVES;
     static_assert(VPFX_FILL_CLAIM == 1 || VPFX_FILL_CLAIM == WV, "a full block is one unit per wave of the workgroup");
     // units per block = working waves per workgroup: the full 16 once there is a block for every CU, else halved until there is (at least
@@ -979,7 +981,6 @@ int launch_fill_nv(vp_ctx* c, int mode, const FillPtrs& P, int math)
     { int rc = chain_begin(c, P, mode, ch); if (rc) return rc; }
     if (c->h_meta.occupied == 0) return VP_OK;
     const dim3 grid(c->h_meta.occupied * TPM);
-    VP_HIP(hipMemsetAsync(c->d_work_counter, 0, sizeof(int), c->stream));
     const int tl = 0;
     return math == 1 ? launch_fill_chain<NV, 1, GEN>(c, mode, P, ch, grid, tl) : math == 2 ? launch_fill_chain<NV, 2, GEN>(c, mode, P, ch, grid, tl)
                                                                                           : launch_fill_chain<NV, 0, GEN>(c, mode, P, ch, grid, tl);

@@ -257,7 +257,7 @@ int  launch_build_cube_u8(vp_ctx* c, const void* d_cube_r8, int S);             
 int  cube_u8_pitch(int S);                                                            // row pitch of the padded byte table
 size_t cube_u8_bytes(int S);                                                          // 6 (S+2) rows of that pitch, rounded up to 16
 int  launch_fill_one(vp_ctx* c, int xx, int yy, int zz);
-int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v);                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
+int  launch_fill_value(vp_ctx* c, float* d, size_t n, float v, int* zero_word = nullptr);   // (zero_word: an int the same launch resets)                             // FillMetavoxel(xx, yy, zz)   VPR.cs:559
 int  launch_fill(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out);  // mode 0 fused, 1 local, 2 finish
 // fill_generic.hip: the same for a voxel count that is not 16 / 32 / 64 (run-time nv; called by launch_fill / launch_fill_one)
 int  launch_fill_generic(vp_ctx* c, int mode, const float* d_light_in, float* d_light_out, int math, bool lds);
