@@ -80,7 +80,7 @@ for src in ("fill", "raymarch"):
     dm = demangle(list(fns))
     for mangled, body in fns.items():
         name = dm[mangled].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        if re.match(r"k_fill_lds<(32|64), 0, 1, false>|k_raymarch<(32|64), false, false, false, true>|k_fill<(32|64), 0, 0, true>", name):
+        if re.match(r"k_fill_lds<(32|64), 0, 1, false(, false)?>|k_raymarch<(32|64), false, false, false, true>|k_fill<(32|64), 0, 0, true(, false)?>", name):
             out["kernels"][name] = mix(body)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k, v in out["kernels"].items(): print(k, {c: round(d["avg_issue_cycles"], 2) for c, d in v.items()})

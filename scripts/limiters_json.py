@@ -3,7 +3,7 @@
 profiles/limiters_<cfg>_<cubemap>.json under the same kernel-source fingerprint as the traffic file; bench.py reports them as
 `roofline.limiter` only while the fingerprint still matches.  usage: limiters_json.py out.json pass1.db pass2.db ...
 or: limiters_json.py out.json earlier_limiters.json   (recompute the derived figures from the raw counter means an earlier run of this script kept,
-e.g. once profiles/r04_isa_mix.json has been regenerated for the sources that run profiled; the fingerprint stays the one recorded there)"""
+e.g. once profiles/r05_isa_mix.json has been regenerated for the sources that run profiled; the fingerprint stays the one recorded there)"""
 import hashlib, json, os, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_sources_sha():
@@ -35,14 +35,14 @@ for db in ([] if RECORDED_SHA else sys.argv[2:]):
         con.close()
 SIMDS = 1024
 try:
-    _m = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_mix.json")))
+    _m = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_mix.json")))
     ISA_MIX = _m["kernels"] if _m.get("kernel_sources_sha") in (None, kernel_sources_sha()) else {}
-    if not ISA_MIX: print("profiles/r04_isa_mix.json was made on other kernel sources: no valu_issue fraction (rerun scripts/isa_mix.py)", file=sys.stderr)
+    if not ISA_MIX: print("profiles/r05_isa_mix.json was made on other kernel sources: no valu_issue fraction (rerun scripts/isa_mix.py)", file=sys.stderr)
 except Exception:
     ISA_MIX = {}
 if RECORDED_SHA and RECORDED_SHA != kernel_sources_sha():
     sys.exit(f"the counters were measured on kernel sources {RECORDED_SHA}, the tree is at {kernel_sources_sha()}: not re-deriving across sources")
-out = {"kernel_sources_sha": kernel_sources_sha(), "source": "rocprofv3 --pmc passes of the bench command (scripts/gpu_prof_r4.sh)"}
+out = {"kernel_sources_sha": kernel_sources_sha(), "source": "rocprofv3 --pmc passes of the bench command (scripts/gpu_prof_r5.sh)"}
 for k, c in ctr.items():
     g = lambda name: c.get(name)
     d = {"instantiation": c["instantiation"]}
@@ -54,7 +54,7 @@ for k, c in ctr.items():
     # transcendental) whatever the opcode's real issue rate (2.2-2.7 / 4.3 / 8.25 cycles per wave64 instruction per SIMD; scripts/gpu_valu_class.sh,
     # profiles/r04_valu_class_calibration.txt), so round 3's `x 4 / SIMD-cycles` exceeded 1.  The fraction reported here prices the class
     # counters of this run (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, _INT32, _CVT; the rest = SQ_INSTS_VALU minus those) with the average issue
-    # cycles of that class IN THIS KERNEL (loop-weighted static opcode mix of its ISA x the measured per-opcode rates: profiles/r04_isa_mix.json).
+    # cycles of that class IN THIS KERNEL (loop-weighted static opcode mix of its ISA x the measured per-opcode rates: profiles/r05_isa_mix.json).
     mix = ISA_MIX.get(c["instantiation"])
     cls = {n: g("SQ_INSTS_VALU_" + n) for n in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")}
     if mix and g("SQ_INSTS_VALU") is not None and all(v is not None for v in cls.values()) and cyc:
@@ -68,7 +68,7 @@ for k, c in ctr.items():
                            "frac_probe_rates": need_probe / (SIMDS * cyc),
                            "wave_instructions_by_class": cls,
                            "avg_issue_cycles_by_class": {k: round(mix.get(k, {}).get("avg_issue_cycles", 4.3), 3) for k in cls},
-                           "source": "class counters of this profile x profiles/r04_isa_mix.json (opcode rates: profiles/r04_valu_classes.json)"}
+                           "source": "class counters of this profile x profiles/r05_isa_mix.json (opcode rates: profiles/r04_valu_classes.json)"}
     if g("SQ_THREAD_CYCLES_VALU") is not None and g("SQ_ACTIVE_INST_VALU"): d["lanes_enabled_per_valu_fraction"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"): d["lds_conflict_share_of_lds_cycles"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     if g("SQ_LDS_IDX_ACTIVE") is not None and cyc: d["lds_pipe_busy_fraction"] = g("SQ_LDS_IDX_ACTIVE") / (256.0 * cyc)
