@@ -5,6 +5,8 @@ and VPFX_TEST_RCCL_SHIM=1.  Two groups:
   * the stand-in itself: it moves the right bytes, and it REPORTS -- instead of hanging -- exactly the usage errors that hang or corrupt on the
     real library: issue orders that differ between ranks, byte counts that differ across a matched send / receive, all-gathers that disagree,
     an in-place all-gather whose send buffer is not recvbuff + rank * count, a peer that never shows up;
+  * libvpfx's fan-out in the launch style of `bench.py` under torch.distributed.run -- ONE context per rank (num_devices 1, world_size N,
+    first_rank r, a shared ncclUniqueId), here one host thread per rank instead of one process;
   * libvpfx's fan-out on it: an injected asynchronous communicator error (ncclCommGetAsyncError != success while the stream is stalled) aborts
     the context with VP_ERR_RCCL (multi.cpp kid_wait), and the abort-vs-owner race of the communicator handle is exercised.
 """
@@ -257,3 +259,49 @@ def test_identical_argument_errors_on_every_rank_do_not_abort_the_context():
     assert ei.value.code == abi.VP_ERR_BAD_ARG
     assert np.abs(_frame(m, sc) - ref).max() <= 2e-5                       # the same context renders the frame afterwards
     m.close(); single.close()
+
+
+# ---- one context per rank: what `python -m torch.distributed.run ... bench.py --gpus N` creates, with threads for the processes -----------------------
+@pytest.mark.parametrize("world,flags", [(2, 0), (3, abi.VP_MULTI_EXCHANGE_ALL_GATHER), (4, 0)])
+def test_one_context_per_rank_like_one_process_per_gpu(world, flags):
+    """Every rank owns its OWN vp_context (devices = [0], world_size = N, first_rank = r, ncclCommInitRank on a shared unique id) and makes the
+    same calls in the same order -- bench.py's multi-process path.  Nothing may rely on the other ranks being local: the slab cuts, the
+    re-cut from the measured per-slice work, the votes and both exchanges have to agree through the communicator alone.  Rank 0 shows the frame."""
+    sc = S.make_scene("C1", cubemap="r8")
+    single = E.Engine(sc.config())
+    ref = _frame(single, sc)
+    sc2 = S.make_scene("C1", cubemap="r8")
+    sc2.set_camera((2.0, 1.0, -1.5))
+    ref2 = single.raymarch(sc2.camera(), sc2.raymarch_params())
+    uid = E.rccl_unique_id()
+    mflags = flags | abi.VP_MULTI_TEST_HOOKS | abi.VP_MULTI_TEST_SHARED_DEVICE
+
+    def rank(r):
+        def body():
+            eng = E.Engine(sc.config(devices=[0], world_size=world, first_rank=r, multi_flags=mflags, rccl_unique_id=uid))
+            img = _frame(eng, sc)
+            info0 = eng.multi_info()
+            eng.rebalance()                                   # bench.py's warm-up: record per-slice samples, re-cut at the next bin
+            img_b = eng.raymarch(sc2.camera(), sc2.raymarch_params())
+            eng.bin_resident()
+            eng.fill(sc.fill_params())
+            img2 = eng.raymarch(sc2.camera(), sc2.raymarch_params())
+            info = eng.multi_info()
+            st = eng.stats()
+            eng.sync()
+            eng.close()
+            return img, img_b, img2, info0, info, st
+        return body
+    res = run_ranks([rank(r) for r in range(world)])
+    img, img_b, img2, info0, info, st = res[0]
+    assert np.abs(img - ref).max() <= 2e-5
+    assert np.abs(img_b - ref2).max() <= 2e-5 and np.abs(img2 - ref2).max() <= 2e-5
+    for r in range(world):
+        i0, i1 = res[r][3], res[r][4]
+        assert i1["world_size"] == world and i1["num_local"] == 1 and i1["first_rank"] == r and i1["rccl_ranks"] == world
+        assert i0["slab_cuts"] == info0["slab_cuts"] and i1["slab_cuts"] == info["slab_cuts"], "the ranks disagree on the slab cut"
+    cuts = info["slab_cuts"]
+    assert cuts[0] == 0 and cuts[-1] == sc.N[2] and all(b > a for a, b in zip(cuts, cuts[1:]))
+    s1 = single.stats()
+    assert st["particles"] == s1["particles"]
+    single.close()
