@@ -165,6 +165,11 @@ def main():
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the untimed content variants after the timed region (float cube map, coloured ambient, +x view: `variants` in the JSON line)")
     args = ap.parse_args()
+    # stdout carries the JSON line and nothing else: everything any library prints there (gloo announces its connections on stdout from C++,
+    # one line per rank, interleaved) is sent to stderr for the rest of the run; rank 0 writes the line to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
@@ -500,7 +505,8 @@ def main():
             out["speedup_vs_cpu"] = (out["value_formula_units"] or out["value"]) / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_note"] = ("(voxels + FORMULA samples) per second, GPU frame / CPU port; in executed samples the GPU figure is `value` "
                                           f"({out['value'] / out['cpu_baseline']['value']:.0f}x), which credits the early-out with nothing")
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if multi_process:
         dist.destroy_process_group()

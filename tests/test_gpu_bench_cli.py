@@ -19,8 +19,8 @@ def _bench(*args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "4", "--warmup", "2"] + list(args), cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1500:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-1500:]     # the JSON line and nothing else on stdout
     d = json.loads(lines[0])
     for k in KEYS:
         assert k in d, k
@@ -78,3 +78,51 @@ def test_one_process_per_gpu_launch_meets_in_rccl_and_fails_cleanly_on_one_gpu()
     assert r.returncode != 0
     assert out.count("VP_ERR_RCCL") >= 2, out[-3000:]                      # both ranks
     assert "Duplicate GPU detected" in out, out[-3000:]
+
+
+TOOLS = os.path.join(ROOT, "tests", "tools")
+MP_SHIM = os.path.join(TOOLS, "_build", "libfake_rccl_mp.so")
+
+
+def _build_mp_shim():
+    src = os.path.join(TOOLS, "fake_rccl_mp.cpp")
+    if os.path.exists(MP_SHIM) and os.path.getmtime(MP_SHIM) >= os.path.getmtime(src):
+        return
+    os.makedirs(os.path.dirname(MP_SHIM), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", MP_SHIM,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"], check=True)
+
+
+@pytest.mark.parametrize("n,exchange", [(2, "tiles"), (4, "all_gather")])
+def test_one_process_per_gpu_launch_runs_to_its_json_line_on_the_multiprocess_standin(n, exchange):
+    """The command the driver measures scaling with -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- run to its end on
+    this ONE GPU: N processes, each with its own context (num_devices 1, world_size N, first_rank = RANK), the unique id from rank 0 over gloo,
+    ncclCommInitRank inside libvpfx.  The real librccl refuses ranks that share a device (previous test), so libvpfx is pointed (VPFX_RCCL_LIBRARY)
+    at tests/tools/fake_rccl_mp.cpp, which stages the bytes through a shared segment between the processes under RCCL's matching rules.  Checked:
+    one JSON line from rank 0 with the contract's keys, N RCCL ranks, the library's slab cut, per-rank figures from every process, and the sharded
+    frame equal to the 1-GPU frame rendered on rank 0 before the timed region."""
+    import socket
+    _build_mp_shim()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, MASTER_ADDR="127.0.0.1",
+               VPFX_RCCL_LIBRARY=MP_SHIM, FAKE_RCCL_TIMEOUT_MS="60000")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-gpu", "--config", "C1", "--steps", "4",
+                        "--warmup", "2", "--exchange", exchange],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-3000:]    # rank 0's JSON line and NOTHING else on stdout (gloo's chatter goes to stderr)
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    c = d["config"]
+    assert d["n_gpus"] == n and c["rccl_ranks"] == n and "one process per GPU" in c["launch"] and "ncclCommInitRank" in c["launch"]
+    assert len(c["slabs"]) == n and c["slabs"][0][0] == 0 and c["slabs"][-1][1] == 8
+    assert c["max_abs_rgba_diff_vs_1gpu_frame"] is not None and c["max_abs_rgba_diff_vs_1gpu_frame"] <= 2e-5
+    pr = d["per_rank"]
+    assert len(pr["samples"]) == n and sum(pr["samples"]) >= c["samples_per_step"] > 0
+    ms = pr["kernel_ms_bin_fill_raymarch_finish"]
+    assert all(row[1] > 0 for row in ms) and ms[0][3] == 0 and all(row[3] > 0 for row in ms[1:])     # every process reported; finish pass on ranks > 0 only
+    assert d["scaling"] == "strong" and d["value"] > 0 and exchange in c["parallelism"]

@@ -76,8 +76,16 @@ struct Rccl {
         std::lock_guard<std::mutex> lk(m);
         if (tried) return so != nullptr;
         tried = true;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+        // VPFX_RCCL_LIBRARY=<path>: the RCCL build to use instead of the one the loader finds by name (a site's own build; the tests' multi-process
+        // stand-in, which a process that has torch -- and with it the real librccl.so.1 -- mapped can only reach by path).  No fallback when set.
+        const char* forced = getenv("VPFX_RCCL_LIBRARY");
+        if (forced && *forced) {
+            so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!so) { err = std::string("VPFX_RCCL_LIBRARY=") + forced + " cannot be loaded (" + (dlerror() ? dlerror() : "?") + ")"; return false; }
+        } else {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+        }
         if (!so) { err = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")"; return false; }
         bool ok = true;
         auto sym = [&](auto& fn, const char* name) {
