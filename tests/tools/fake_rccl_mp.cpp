@@ -118,6 +118,12 @@ struct Lock {
     void wake() { pthread_cond_broadcast(&h->cv); }
 };
 
+// re-acquire the segment mutex after a copy made outside it (same owner-death handling as Lock)
+void relock(ShHdr* h)
+{
+    if (pthread_mutex_lock(&h->m) == EOWNERDEAD) { pthread_mutex_consistent(&h->m); h->aborted = 1; }
+}
+
 timespec deadline_in_ms(long ms)
 {
     timespec t;
@@ -189,9 +195,10 @@ ncclResult_t leave_with(Comm* c, Lock& lk, ncclResult_t res)
 ncclResult_t status_of(Comm* c, bool timed_out, long timeout_ms)
 {
     ShHdr* h = c->h;
-    if (h->error[0]) return fail(ncclInvalidUsage, h->error);
+    if (h->error[0] && !timed_out) return fail(ncclInvalidUsage, h->error);
     if (h->aborted) return fail(ncclInternalError, "communicator aborted while rank " + std::to_string(c->rank) + " waited in " + describe(h, c->rank));
     if (timed_out) {
+        snprintf(h->error, sizeof h->error, "rank %d timed out after %ld ms: the communicator is unusable from here on", c->rank, timeout_ms);
         std::string s = "time-out: rank " + std::to_string(c->rank) + " waited " + std::to_string(timeout_ms) + " ms in " + describe(h, c->rank) + "; peers:";
         for (int p = 0; p < h->n; ++p) if (p != c->rank) s += "\n    rank " + std::to_string(p) + ": " + describe(h, p);
         return fail(ncclSystemError, s);
@@ -237,7 +244,7 @@ ncclResult_t run_p2p(Comm* c, const std::vector<Pending>& pend)
             const ShXfer y = R.x[i];
             pthread_mutex_unlock(&h->m);
             const hipError_t e = y.bytes ? hipMemcpy(pend[i].ptr, outbox(c, y.peer) + y.off, y.bytes, hipMemcpyHostToDevice) : hipSuccess;
-            pthread_mutex_lock(&h->m);
+            relock(h);
             if (e != hipSuccess) { snprintf(h->error, sizeof h->error, "rank %d: HIP error while taking a message: %s", c->rank, hipGetErrorString(e)); break; }
             R.x[i].state = 2;
             h->r[y.peer].x[y.partner].state = 2;
@@ -281,7 +288,7 @@ ncclResult_t run_allgather(Comm* c, const void* sendbuff, void* recvbuff, uint64
     hipError_t e = hipSuccess;
     for (int p = 0; p < h->n && e == hipSuccess; ++p)
         if (p != c->rank && blk) e = hipMemcpy((char*)recvbuff + (uint64_t)p * blk, outbox(c, p), blk, hipMemcpyHostToDevice);
-    pthread_mutex_lock(&h->m);
+    relock(h);
     if (e != hipSuccess) snprintf(h->error, sizeof h->error, "rank %d: HIP error while taking all-gather blocks: %s", c->rank, hipGetErrorString(e));
     ++h->ag_done[slot];
     lk.wake();
@@ -351,13 +358,18 @@ FAKE_EXPORT ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniq
     Comm* c = new Comm();
     c->h = h; c->base = static_cast<char*>(p); c->rank = rank; c->path = path;
     if (hipGetDevice(&c->dev) != hipSuccess) { delete c; munmap(p, total); return fail(ncclUnhandledCudaError, "hipGetDevice"); }
+    int bad = 0;
     {
         Lock lk(h);
         if (h->n == 0) h->n = nranks;
-        if (h->n != nranks) { munmap(p, total); delete c; return fail(ncclInvalidArgument, "ranks of one unique id disagree on the communicator size"); }
-        if (h->r[rank].joined) { munmap(p, total); delete c; return fail(ncclInvalidUsage, "rank " + std::to_string(rank) + " joined twice"); }
-        h->r[rank].joined = 1;
-        lk.wake();
+        if (h->n != nranks) bad = 1;
+        else if (h->r[rank].joined) bad = 2;
+        else { h->r[rank].joined = 1; lk.wake(); }
+    }
+    if (bad) {                                   // (unmapped only after the lock on the segment has been released)
+        munmap(p, total); delete c;
+        return bad == 1 ? fail(ncclInvalidArgument, "ranks of one unique id disagree on the communicator size")
+                        : fail(ncclInvalidUsage, "rank " + std::to_string(rank) + " joined twice");
     }
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;                          // (non-blocking: the first operation waits for the ranks that have not joined yet)
