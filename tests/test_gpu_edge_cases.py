@@ -106,6 +106,19 @@ def test_odd_grids(dims):
     check(S.make_scene("odd", dims=dims))
 
 
+@pytest.mark.parametrize("steps,soft", [(1, 1), (2, 20), (3, 1), (7, 1000), (128, 5), (200, 20), (1000, 3)])
+def test_extreme_step_counts_and_soft_distances(steps, soft):
+    """_NumRaymarchStepsPerMV and _SoftDistance are inspector ints (VPR.cs:92-93): one lattice point per metavoxel diagonal up to a thousand (every
+    visit then outruns the sample loops' unrolling: the 4 / 2 / 1 remainder paths), a fade that covers one lattice index or every sample of the ray."""
+    sc = S.make_scene("steps", dims=(3, 16, 150, 72, 56))
+    sc.steps, sc.soft_distance = steps, soft
+    for cam in ((1.1, 0.7, -1.6), (0.2, 0.1, 0.3)):                  # outside, and inside the grid (tCamera clamps tEntry)
+        D = 0.8 * 3 * sc.mv_scale
+        sc.set_camera(tuple(D * x for x in cam))
+        check(sc, exact=True)
+        check(sc, exact=False)
+
+
 def test_non_cubic_grid():
     sc = S.make_scene("nc", dims=(6, 16, 300, 96, 64))
     sc.N = (4, 6, 5)
