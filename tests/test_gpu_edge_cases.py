@@ -21,7 +21,7 @@ def both(sc, **kw):
     return o, g
 
 
-def check(sc, exact=True, rgba_tol=1e-3, **kw):
+def check(sc, exact=True, rgba_tol=1e-3, near_zero_abs=0.0, **kw):
     o, g = both(sc, exact=exact, early_out=False, **kw)
     np.testing.assert_array_equal(o.bin_counts(), g.bin_counts())
     co = o.bin_counts()
@@ -30,7 +30,14 @@ def check(sc, exact=True, rgba_tol=1e-3, **kw):
         if exact:
             assert np.array_equal(a, b), (xx, yy, zz)
         else:
-            assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+            du = np.abs(a.astype(np.int32) - b.astype(np.int32))
+            if du.max() > 1:
+                # default math: <= 1 fp16 ulp, except in near-zero values, where the smoothstep's t = 10/3 - (40/3) d2 / net cancels and the
+                # reciprocal's last bit shows as a few ulp of an almost-zero density: bounded ABSOLUTELY there (the rule of the randomised
+                # sweep, scripts/fuzz_parity.py); the caller passes the bound it accepts (0 = none)
+                fa, fb = o.read_brick(xx, yy, zz).astype(np.float32), g.read_brick(xx, yy, zz).astype(np.float32)
+                worst_abs = float(np.abs(fa - fb)[du > 1].max())
+                assert worst_abs <= near_zero_abs, (xx, yy, zz, int(du.max()), worst_abs)
     np.testing.assert_allclose(g.read_lightmap(), o.read_lightmap(), rtol=1e-5, atol=1e-9)
     io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
     assert np.abs(io - ig).max() <= rgba_tol
@@ -117,6 +124,47 @@ def test_extreme_step_counts_and_soft_distances(steps, soft):
         sc.set_camera(tuple(D * x for x in cam))
         check(sc, exact=True)
         check(sc, exact=False)
+
+
+@pytest.mark.parametrize("case", ["fov_10", "fov_150", "image_1x1", "image_7x3", "opacity_0", "opacity_5", "displacement_0", "ambient_0", "far_grid",
+                                  "near_far_tight", "tiny_mv", "huge_mv"])
+def test_inspector_extremes(case):
+    """The other inspector fields at the ends of their useful ranges (VPR.cs:84-97 and the camera): field of view, image sizes below one wave's
+    pixel block, opacityFactor 0 (an empty cloud that still occupies its metavoxels) and 5 (saturates within a voxel), no displacement, black
+    ambient, a grid 5 km from the origin (float cancellation in every world-space difference), clip planes that cut the cloud, metavoxels of
+    3 cm and of 300 m."""
+    sc = S.make_scene(case, dims=(3, 16, 120, 64, 48))
+    cam_scale = 1.0
+    if case == "fov_10": sc.fov_y_deg = 10.0
+    elif case == "fov_150": sc.fov_y_deg = 150.0
+    elif case == "image_1x1": sc.width, sc.height = 1, 1
+    elif case == "image_7x3": sc.width, sc.height = 7, 3
+    elif case == "opacity_0": sc.opacity_factor = 0.0
+    elif case == "opacity_5": sc.opacity_factor = 5.0
+    elif case == "displacement_0": sc.displacement_scale = 0.0
+    elif case == "ambient_0": sc.ambient = (0.0, 0.0, 0.0)
+    elif case == "far_grid":
+        off = np.array([5000.0, -3000.0, 4000.0], dtype=np.float32)
+        sc.grid_center = (np.asarray(sc.grid_center, dtype=np.float32) + off).astype(np.float32)
+        m = np.array(sc.psys_local_to_world, dtype=np.float32).copy()
+        m[12:15] += off                                                    # column-major: the translation column
+        sc.psys_local_to_world = m
+    elif case in ("tiny_mv", "huge_mv"):
+        k = 0.01 if case == "tiny_mv" else 100.0
+        cam_scale = k
+        sc.mv_scale = float(sc.mv_scale * k)
+        for f in ("position",):
+            sc.particles[f] *= np.float32(k)
+        sc.particles["size"] *= np.float32(k)
+        sc.near, sc.far = sc.near * k, sc.far * k
+    D = 0.8 * 3 * sc.mv_scale
+    gc = np.asarray(sc.grid_center, dtype=np.float64)
+    sc.set_camera(tuple(gc + D * np.array([1.1, 0.6, -1.5])), target=tuple(gc))
+    if case == "near_far_tight":
+        sc.near, sc.far = 1.2 * D, 2.2 * D                                 # both planes inside the cloud's depth range
+    check(sc, exact=True, rgba_tol=1e-3)
+    # (opacityFactor 5 scales the near-zero densities at the smoothstep's far edge by 125: the few-ulp deviation of default math there, see check)
+    check(sc, exact=False, rgba_tol=1e-3, near_zero_abs=1e-4 if case == "opacity_5" else 0.0)
 
 
 def test_non_cubic_grid():
