@@ -369,6 +369,51 @@ def test_fanout_edge_cases_match_the_single_context(case):
     m.close(); single.close()
 
 
+@pytest.mark.parametrize("case,world,flags", [("image_1x1", 4, 0), ("image_1x1", 3, abi.VP_MULTI_EXCHANGE_ALL_GATHER), ("image_7x3", 8, 0),
+                                              ("image_7x3", 2, abi.VP_MULTI_EXCHANGE_ALL_GATHER), ("one_step", 4, 0), ("thousand_steps", 3, 0),
+                                              ("odd_voxels_with_occluders", 4, 0), ("odd_voxels_with_occluders", 3, abi.VP_MULTI_EXCHANGE_ALL_GATHER)])
+def test_fanout_at_the_extremes_of_the_frame_parameters(case, world, flags):
+    """The exchange pieces are cut from the image: images smaller than one piece per rank (1 x 1, 7 x 3 pixels on up to 8 ranks) must still come
+    back whole; one lattice step per metavoxel and a thousand; a voxel count that is not a multiple of the fill's 8 x 8 tiles together with
+    occluder boxes (light depth map per slab, eye depth map in front of the slab kernels)."""
+    if case == "odd_voxels_with_occluders":
+        sc = S.make_scene(case, dims=(8, 12, 400, 96, 72))
+    else:
+        sc = S.make_scene("C1", cubemap="r8")
+    if case == "image_1x1": sc.width, sc.height = 1, 1
+    elif case == "image_7x3": sc.width, sc.height = 7, 3
+    elif case == "one_step": sc.steps = 1
+    elif case == "thousand_steps": sc.steps, sc.width, sc.height = 1000, 48, 32
+    boxes = None
+    D = 0.8 * sc.N[0] * sc.mv_scale
+    if case == "odd_voxels_with_occluders":
+        boxes = [S.make_box((0.0, -0.2 * D, 0.0), (2.0 * D, 0.02 * D, 2.0 * D)),
+                 S.make_box((0.15 * D, 0.1 * D, -0.3 * D), (0.1 * D, 0.12 * D, 0.1 * D), S.quat_to_matrix((0.2, -0.1, 0.3, 0.927)).T)]
+
+    def frame(eng):
+        eng.set_frame(sc.light_to_world, sc.grid_center)
+        if boxes is not None:
+            eng.set_occluders(boxes)
+        eng.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        eng.fill(sc.fill_params())
+        return eng.raymarch(sc.camera(), sc.raymarch_params())
+    single = E.Engine(sc.config())
+    m = _fanout(sc, world, flags)
+    ref, img = frame(single), frame(m)
+    assert img.shape == (sc.height, sc.width, 4) and np.abs(img - ref).max() <= 2e-5
+    assert ref.any() or case == "image_1x1"
+    io = frame(O.Oracle(sc.config()))
+    # (with occluders: a pixel whose box-edge depth differs in the last ulp may flip a whole-metavoxel rejection -- a handful of pixels at most)
+    assert (np.abs(img - io).max(axis=-1) > 1e-3).sum() <= (3 if boxes is not None else 0)
+    if boxes is not None:
+        np.testing.assert_allclose(m.read_lightmap(), single.read_lightmap(), rtol=2e-5, atol=1e-9)
+        assert (single.render_light_depth() < 1).mean() > 0.05, "the occluders were meant to shadow part of the light map"
+    # another camera on the same contexts (the pieces do not depend on it; the slabs' phase split does)
+    sc.set_camera((2.0, 1.0, -1.5) if boxes is None else (0.5 * D, 0.4 * D, -0.9 * D))
+    assert np.abs(m.raymarch(sc.camera(), sc.raymarch_params()) - single.raymarch(sc.camera(), sc.raymarch_params())).max() <= 2e-5
+    m.close(); single.close()
+
+
 def test_a_rank_that_leaves_an_exchange_aborts_the_context_instead_of_hanging_it():
     """VERDICT r3 missing #2 / ADVICE r3: no rank may hang because a peer left an exchange.  VP_MULTI_TEST_DROP_SEND (test hook, opt-in through
     VP_MULTI_TEST_HOOKS) makes the last rank silently skip the first message it should send (its slot of the tau all-gather); with a 400 ms

@@ -49,12 +49,13 @@ def run_child(args, tmp_path, timeout=1500):
 
 def test_fanout_tests_on_the_rccl_branch_with_the_checking_standin(tmp_path):
     """The fan-out tests of tests/test_gpu_multi.py -- worlds of 2, 3, 4 and 8 ranks, both exchange forms, hand-off groups, cameras with and
-    without a straddling slab, slab re-cuts (the profile all-gather), 300 frames on 8 ranks, the degenerate slabs, the C3 grid in eight slabs --
+    without a straddling slab, slab re-cuts (the profile all-gather), 300 frames on 8 ranks, the degenerate slabs, images smaller than one exchange
+    piece per rank, the C3 grid in eight slabs --
     with use_rccl = true; communicators alternately from ncclCommInitAll and from ncclGetUniqueId + grouped ncclCommInitRank."""
     sel = ("test_fanout_matches_single_context_and_oracle or test_serial_handoff_chain or test_handoff_with_a_camera_inside or "
-           "test_config4_benchmark_grid_in_eight_slabs or test_fanout_many_frames or test_fanout_edge_cases")
+           "test_config4_benchmark_grid_in_eight_slabs or test_fanout_many_frames or test_fanout_edge_cases or test_fanout_at_the_extremes")
     passed, st, tail = run_child(["tests/test_gpu_multi.py", "-k", sel], tmp_path)
-    assert passed == 4 + 1 + 3 + 1 + 1 + 4, tail
+    assert passed == 4 + 1 + 3 + 1 + 1 + 4 + 8, tail
     # the RCCL branch really ran, on the stand-in, and the stand-in had nothing to report
     assert st["communicators"] >= 60 and st["p2p_groups"] > 1000 and st["all_gathers"] > 100 and st["bytes"] > 1 << 30, st
     assert st["errors"] == 0 and st["aborts"] == 0, st
