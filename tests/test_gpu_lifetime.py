@@ -82,3 +82,34 @@ def test_pinned_buffers_and_async_images_come_and_go():
         e.unpin(img)
     assert free0 - _free_bytes() < 16 << 20 and _open_fds() - fds0 <= 4
     e.close()
+
+
+def test_independent_contexts_on_concurrent_host_threads():
+    """Four host threads, each with its OWN context (its own stream), different scenes, many frames at once on one GPU: no state is shared
+    between contexts, so every thread must keep rendering exactly what its scene renders alone (the library's only process-wide state is
+    read-only after load; vp_last_error is per context)."""
+    scenes = [S.make_scene("C1", cubemap="r8"), S.make_scene("T0"), S.make_scene("a", dims=(4, 12, 300, 80, 60)), S.make_scene("b", dims=(3, 32, 200, 64, 64))]
+    refs = []
+    for sc in scenes:
+        e = E.Engine(sc.config()); refs.append(_frame(e, sc)); e.close()
+    errors = []
+
+    def worker(i):
+        try:
+            sc = scenes[i]
+            e = E.Engine(sc.config())
+            for k in range(25):
+                img = _frame(e, sc)
+                if not np.array_equal(img, refs[i]):
+                    errors.append((i, k, float(np.abs(img - refs[i]).max())))
+                    break
+            e.close()
+        except Exception as ex:                            # noqa: BLE001 -- reported to the main thread
+            errors.append((i, repr(ex)))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(scenes))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+        assert not t.is_alive()
+    assert not errors, errors
