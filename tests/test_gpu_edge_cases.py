@@ -179,6 +179,16 @@ def test_border_sizes(border):
     check(sc)
 
 
+@pytest.mark.parametrize("nv,border", [(16, 7), (9, 4), (32, 15), (64, 31), (5, 2), (3, 1), (2, 0)])
+def test_widest_borders_and_smallest_bricks(nv, border):
+    """numBorderVoxels up to the largest value vp_create accepts (2 b < nv: an interior of one or two voxels, VPR.cs:139 divides by nv - 2 b) and
+    the smallest bricks: the texel lattice of the ray-march then spans one or two voxels, the border index of the light propagation sits next to
+    the brick's last slice, and at nv = 2 / 3 every 8 x 8 fill tile is mostly overhang."""
+    sc = S.make_scene("wb", dims=(3, nv, 120, 72, 56), border=border)
+    check(sc, exact=True)
+    check(sc, exact=False)
+
+
 def test_nv64_extension():
     """64^3-voxel bricks (beyond the reference's NUM_VOXELS 32 cap, Q21): two 32-slice register chunks."""
     sc = S.make_scene("n64", dims=(3, 64, 40, 96, 64))
