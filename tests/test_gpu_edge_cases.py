@@ -189,6 +189,27 @@ def test_widest_borders_and_smallest_bricks(nv, border):
     check(sc, exact=False)
 
 
+@pytest.mark.parametrize("axis", ["+z", "-z", "+x", "-x", "+y", "-y", "on_cell_plane", "in_corner"])
+def test_axis_aligned_views_of_an_axis_aligned_grid(axis):
+    """Light axes = world axes, grid centred on the origin, the camera EXACTLY on a grid axis and an odd image size, so that the centre pixel's ray has
+    two direction components that are exactly zero (1 / 0 in the slab tests: IntersectBox relies on min / max dropping the NaN of inf x 0,
+    RM.shader:95-118; the cell walk never steps along such an axis), whole pixel columns run inside one cell plane, and ties between cell faces are
+    exact.  Also a camera sitting exactly ON a plane between two metavoxel layers, and one exactly in a grid corner."""
+    sc = S.make_scene("axis", dims=(4, 16, 300, 65, 49))
+    sc.light_to_world = S.to_colmajor16(np.eye(4))
+    sc.grid_center = np.zeros(3, dtype=np.float32)
+    D = 0.8 * 4 * sc.mv_scale
+    up = (0.0, 1.0, 0.0)
+    pos = {"+z": (0, 0, D), "-z": (0, 0, -D), "+x": (D, 0, 0), "-x": (-D, 0, 0), "+y": (0, D, 0), "-y": (0, -D, 0),
+           "on_cell_plane": (sc.mv_scale * 1.0, 0.0, -D), "in_corner": (2 * sc.mv_scale, 2 * sc.mv_scale, -2 * sc.mv_scale)}[axis]
+    if axis in ("+y", "-y"):
+        up = (0.0, 0.0, 1.0)
+    sc.cam_to_world, sc.world_to_cam = S.look_at_camera(pos, (0.0, 0.0, 0.0), up)
+    sc.cam_pos = np.asarray(pos, dtype=np.float32)
+    check(sc, exact=True)
+    check(sc, exact=False)
+
+
 def test_nv64_extension():
     """64^3-voxel bricks (beyond the reference's NUM_VOXELS 32 cap, Q21): two 32-slice register chunks."""
     sc = S.make_scene("n64", dims=(3, 64, 40, 96, 64))
