@@ -210,6 +210,33 @@ def test_axis_aligned_views_of_an_axis_aligned_grid(axis):
     check(sc, exact=False)
 
 
+@pytest.mark.parametrize("z", [-4.5, -1.5, 1.5, 4.5, -7.5, 7.5])
+def test_camera_exactly_between_two_light_axis_layers(z):
+    """zBoundary = clamp(RoundToInt((lsCam.z - lsFirstSlice.z) / s), -1, Nz - 1) (VPR.cs:640-649) with the quotient EXACTLY on .5: Mathf.RoundToInt
+    rounds half to even, so 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 3.5 -> 4 (clamped to 3), -0.5 -> -0 = 0, 4.5 -> 4 (clamped); the phase split of the
+    slabs -- which metavoxels blend OVER, which UNDER -- follows it.  Single context and a fan-out whose slab cuts meet the boundary."""
+    sc = S.make_scene("ztie", dims=(4, 16, 300, 64, 48))
+    sc.light_to_world = S.to_colmajor16(np.eye(4))
+    sc.grid_center = np.zeros(3, dtype=np.float32)
+    pos = (0.4, 0.3, z)
+    sc.cam_to_world, sc.world_to_cam = S.look_at_camera(pos, (5.0, 0.6, z + 0.7))
+    sc.cam_pos = np.asarray(pos, dtype=np.float32)
+    o, g, io, ig = check(sc, exact=True)
+    q = (z - (-6.0)) / 3.0
+    expect = int(min(max(np.round(q), -1), 3))                           # numpy rounds half to even like Mathf.RoundToInt
+    assert g.z_boundary(sc.camera()) == expect == o.z_boundary(sc.camera())
+    m = E.Engine(sc.config(devices=[0] * 4, multi_flags=abi.VP_MULTI_PEER_COPY | abi.VP_MULTI_UNIFORM_SLABS))
+    m.set_frame(sc.light_to_world, sc.grid_center)
+    m.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    m.fill(sc.fill_params())
+    single = E.Engine(sc.config())
+    single.set_frame(sc.light_to_world, sc.grid_center)
+    single.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    single.fill(sc.fill_params())
+    assert np.abs(m.raymarch(sc.camera(), sc.raymarch_params()) - single.raymarch(sc.camera(), sc.raymarch_params())).max() <= 2e-5
+    m.close(); single.close()
+
+
 def test_nv64_extension():
     """64^3-voxel bricks (beyond the reference's NUM_VOXELS 32 cap, Q21): two 32-slice register chunks."""
     sc = S.make_scene("n64", dims=(3, 64, 40, 96, 64))
