@@ -237,6 +237,44 @@ def test_camera_exactly_between_two_light_axis_layers(z):
     m.close(); single.close()
 
 
+@pytest.mark.parametrize("N", [4, 5])
+def test_binning_at_its_ties(N):
+    """A.2's corner cases, made exact: particles ON metavoxel boundaries and centres (pIndex an integer or a half-integer: the (int) truncation and
+    the even-N half-metavoxel skew of Q1 / Q2), radii of exactly 0.5 s, 1.5 s, 2.5 s (RoundToInt rounds half to even: candidate range +-0, +-2, +-2),
+    radius 0.5 s - 1 ulp / + 1 ulp, particles just outside the grid (within and beyond their radius; a negative hi of -0.5 truncates to index 0) and
+    far outside.  Lists, not only counts, must be the oracle's."""
+    s_mv = 3.0
+    sc = S.make_scene("ties", dims=(N, 16, 8, 64, 48))
+    sc.light_to_world = S.to_colmajor16(np.eye(4))
+    sc.grid_center = np.zeros(3, dtype=np.float32)
+    pts, sizes = [], []
+    half = np.float32(0.5 * s_mv)
+    radii = [half, np.float32(1.5 * s_mv), np.float32(2.5 * s_mv), np.nextafter(half, np.float32(0)), np.nextafter(half, np.float32(10)), np.float32(0.3 * s_mv)]
+    coords = [k * 0.5 * s_mv for k in range(-N - 2, N + 3)]                # every half metavoxel from beyond one end of the grid to beyond the other
+    rng = np.random.default_rng(N)
+    for x in coords:
+        for r in radii:
+            y, z = (float(rng.choice(coords)) for _ in range(2))
+            pts.append((x, y, z)); sizes.append(2 * r)
+            pts.append((y, z, x)); sizes.append(2 * r)
+    pts += [(50.0, 0.0, 0.0), (-50.0, 50.0, 50.0), (0.0, 0.0, -(N / 2 + 0.5) * s_mv - 0.4 * s_mv)]
+    sizes += [2.0, 2.0, 1.0 * s_mv]
+    P = len(pts)
+    parts = np.zeros(P, dtype=S.PARTICLE_DTYPE)
+    parts["position"] = np.asarray(pts, dtype=np.float32)
+    parts["size"] = np.asarray(sizes, dtype=np.float32)
+    parts["rotation"] = rng.uniform(0, 360, P).astype(np.float32)
+    parts["lifetime"], parts["startLifetime"] = 3.0, 6.0
+    sc.particles = parts
+    o, g, io, ig = check(sc, exact=True)
+    cnt = o.bin_counts()
+    assert cnt.sum() > P                                               # the big ones cover many metavoxels
+    for zz in range(N):
+        for yy in range(N):
+            for xx in range(N):
+                assert np.array_equal(g.bin_list(xx, yy, zz), o.bin_list(xx, yy, zz)), (xx, yy, zz)
+
+
 def test_nv64_extension():
     """64^3-voxel bricks (beyond the reference's NUM_VOXELS 32 cap, Q21): two 32-slice register chunks."""
     sc = S.make_scene("n64", dims=(3, 64, 40, 96, 64))
