@@ -275,6 +275,26 @@ def test_binning_at_its_ties(N):
                 assert np.array_equal(g.bin_list(xx, yy, zz), o.bin_list(xx, yy, zz)), (xx, yy, zz)
 
 
+@pytest.mark.parametrize("cubemap", ["f32", "r8"])
+def test_cube_map_face_ties(cubemap):
+    """Directions with |x| == |y| EXACTLY (the cube map's edges; App. B.5 / DESIGN 4.5: v_cubeid's tie rule z before y before x is the spec's): light
+    axes = world axes, unrotated particles at the grid centre and at points symmetric in x and y, so that every voxel on a diagonal of such a
+    particle looks along a face edge -- whole planes of ties instead of the measure-zero set a random scene offers."""
+    sc = S.make_scene("ties", dims=(2, 16, 6, 64, 48), cubemap=cubemap)
+    sc.light_to_world = S.to_colmajor16(np.eye(4))
+    sc.grid_center = np.zeros(3, dtype=np.float32)
+    sc.psys_local_to_world = S.to_colmajor16(np.eye(4))
+    pts = [(0.0, 0.0, 0.0), (1.5, 1.5, 0.3), (-1.5, -1.5, -0.6), (1.5, -1.5, 1.0), (0.75, 0.75, -1.5), (0.0, 0.0, 1.5)]
+    parts = np.zeros(len(pts), dtype=S.PARTICLE_DTYPE)
+    parts["position"] = np.asarray(pts, dtype=np.float32)
+    parts["size"] = np.asarray([4.0, 2.0, 2.0, 2.0, 1.0, 2.0], dtype=np.float32)      # powers of two: the divisions by size are exact
+    parts["rotation"] = 0.0
+    parts["lifetime"], parts["startLifetime"] = 3.0, 6.0
+    sc.particles = parts
+    check(sc, exact=True)
+    check(sc, exact=False)
+
+
 def test_nv64_extension():
     """64^3-voxel bricks (beyond the reference's NUM_VOXELS 32 cap, Q21): two 32-slice register chunks."""
     sc = S.make_scene("n64", dims=(3, 64, 40, 96, 64))
