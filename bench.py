@@ -56,7 +56,9 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f in ("fill.hip", "fill_kernels.h", "raymarch.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):   # the kernels (host-side files do not change a counter)
+        # the kernels and every instantiation unit (fill_generic.hip / raymarch_generic.hip decide which kernels run for voxel counts other than
+        # 16 / 32 / 64); host-side .cpp files and occluders.hip (not on any profiled counter) do not change a counter
+        if f in ("fill.hip", "fill_generic.hip", "fill_kernels.h", "raymarch.hip", "raymarch_generic.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):
             h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -477,7 +479,9 @@ def main():
                        "max_abs_rgba_diff_vs_1gpu_frame": shard_err, "reference_frame_skipped": ref_skipped},
             # absolute rates: per stage against that stage's kernel time on the slowest rank (fill = local + finish for N > 1),
             # and for the whole frame (everything incl. the exchanges)
-            "fill_mvoxels_per_s": voxels / fill_t / 1e6,
+            # Mvoxels/s filled = occupied_MVs * nv^3 / t_fill with t_fill = bin + density + propagate (device time)
+            "fill_mvoxels_per_s": voxels / (smax[0] * 1e-3 + fill_t) / 1e6,
+            "fill_kernel_only_mvoxels_per_s": voxels / fill_t / 1e6,
             "raymarch_msamples_per_s": samples / (smax[2] * 1e-3) / 1e6,                    # executed samples (the saturation early-out skips the hidden ones)
             "raymarch_msamples_per_s_formula": (samples_formula / (smax[2] * 1e-3) / 1e6) if samples_formula else None,    # SURVEY 8(d)'s count (what the CPU leg executes) over the same kernel time
             "value_formula_units": ((voxels / update_interval + samples_formula) / (dt / args.steps) / 1e6) if samples_formula else None,   # the frame's work in the units of the CPU leg

@@ -4,6 +4,8 @@
  *   "Particle System Demo" at (0,0,11.2), rotated 180 deg about Y (cone, 10 particles/s...)  :2264-2620  -> vp_emitter_*
  *   directional light quaternion (0.1856,0,0,0.9826) at (0,0,-44.34)                         :6792
  *   main camera at (-10,0,-20) looking down world +z, fov 60, 1024 x 768                     :8965-8967
+ *   the eight Default-layer meshes under "Scene" (0,-5,0): ground / back (cubes scaled (50,1,50)), Cube, Cube 1 and the four cylinders
+ *   (:8623, 1755, 8382, 5462) as occluder solids -> both depth inputs rendered by the library  VPR.cs:184, 204  -> vp_set_occluders2
  *   bin + fill every updateInterval = 2 frames, ray-march every frame                        VPR.cs:186,207
  *   cc -std=c99 -Iinclude examples/demo_scene.c -Lvolumetric-particles-for-unity_amd -lvpfx -lm -o demo_scene
  *   demo_scene [frames] [width] [height]
@@ -55,6 +57,38 @@ int main(int argc, char** argv)
     trs(light_to_world, light_q, light_p);
     trs(psys_to_world, psys_q, psys_p);
     CHECK(vp_set_frame(ctx, light_to_world, grid_center));
+
+    /* the opaque scene: Unity primitives (Cube spans [-0.5,0.5]^3, Cylinder = radius 0.5, height 2 about local y) under their transforms */
+    static const struct { int type; float px, py, pz, sx, sy, sz; int rot_x_90; } prim[8] = {
+        {VP_OCC_BOX,      0.0f,  -1.52f,  0.0f,   50, 1, 50, 0},      /* ground                                  */
+        {VP_OCC_BOX,      0.0f,  24.0f,  24.5f,   50, 1, 50, 1},      /* back: quaternion (0.7071,0,0,0.7071)    */
+        {VP_OCC_BOX,     -5.34f,  6.18f, -11.89f,  1, 1, 1, 0},       /* Cube                                    */
+        {VP_OCC_BOX,      0.0f,   4.57f, -11.0f,   1, 1, 1, 0},       /* Cube 1                                  */
+        {VP_OCC_CYLINDER, -8.24f, 0.0f,   0.0f,    1, 1, 1, 0},       /* Cylinder                                */
+        {VP_OCC_CYLINDER, 0.0f,   0.0f,   0.0f,    1, 1, 1, 0},       /* Cylinder 1                              */
+        {VP_OCC_CYLINDER, 0.0f,   0.0f,   0.0f,    1, 1, 1, 0},       /* Cylinder 2 (coincides with Cylinder 1)  */
+        {VP_OCC_CYLINDER, 1.45f, -1.05f,  9.11f,   1, 1, 1, 0}};      /* Cylinder 3                              */
+    vp_occluder solids[8]; memset(solids, 0, sizeof solids);
+    for (int i = 0; i < 8; ++i) {
+        vp_occluder* o = &solids[i];
+        o->type = prim[i].type;
+        o->center[0] = prim[i].px; o->center[1] = prim[i].py - 5.0f; o->center[2] = prim[i].pz;        /* parent "Scene" at (0,-5,0) */
+        /* rows = the local axes in world space; 90 deg about x: local y -> world z, local z -> world -y */
+        o->axes[0] = 1.0f;
+        if (prim[i].rot_x_90) { o->axes[5] = 1.0f; o->axes[7] = -1.0f; } else { o->axes[4] = 1.0f; o->axes[8] = 1.0f; }
+        o->half_extent[0] = 0.5f * prim[i].sx; o->half_extent[2] = 0.5f * prim[i].sz;
+        o->half_extent[1] = (prim[i].type == VP_OCC_CYLINDER ? 1.0f : 0.5f) * prim[i].sy;
+    }
+    CHECK(vp_set_occluders2(ctx, solids, 8));
+    {
+        const int LW = 10 * 32, LH = 10 * 32;
+        float* ld = (float*)malloc(sizeof(float) * LW * LH);
+        CHECK(vp_render_light_depth(ctx, 0.3f, 1000.0f, 200.0f, ld));
+        int shadowed = 0;
+        for (int i = 0; i < LW * LH; ++i) shadowed += ld[i] < 1.0f;
+        printf("light_depth_shadowed %d\n", shadowed);
+        free(ld);
+    }
 
     vp_emitter* em = NULL;
     vp_emitter_config ec;

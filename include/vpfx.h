@@ -32,11 +32,13 @@
 extern "C" {
 #endif
 
-#define VPFX_ABI_VERSION 5   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
+#define VPFX_ABI_VERSION 6   /* 2: vp_fill_params.cubemap_format (R8 cube maps), per-metavoxel entry points, draw-order view
                                 3: vp_config device list (multi-GPU fan-out inside the library, RCCL), VP_ERR_RCCL, Unity plugin entry points
                                 4: same struct layouts; new: vp_config.reserved[2] = exchange time-out of a fan-out context (abort instead of hang),
                                    VP_MULTI_TEST_HOOKS / VP_MULTI_TEST_DROP_SEND, VP_RM_NO_EARLY_OUT, vp_exchange_plan, vp_unity_clear_slot, vp_unity_register_output_fd
-                                5: same struct layouts; new: the particle source (vp_emitter_*) */
+                                5: same struct layouts; new: the particle source (vp_emitter_*)
+                                6: same struct layouts; new: vp_occluder / vp_set_occluders2 (cylinder and ellipsoid occluders beside boxes).
+                                   Stricter since 5: vp_emitter_config.reserved[] must be 0 and .lifetime finite, <= 1e5 s (VP_ERR_BAD_ARG otherwise) */
 
 typedef enum vp_status {
     VP_OK = 0,
@@ -196,6 +198,26 @@ typedef struct vp_obb {
     float half_extent[3];
 } vp_obb;
 
+/* ABI 6: the general occluder record.  The first 60 bytes ARE a vp_obb; `type` picks the unit solid that
+ * center / axes / half_extent place in the world (local point l = diag(1/half_extent) * axes * (p - center)):
+ *   VP_OCC_BOX        |l.x|, |l.y|, |l.z| <= 1                                (Unity's Cube, mesh 10202: half_extent = scale / 2)
+ *   VP_OCC_CYLINDER   l.x^2 + l.z^2 <= 1, |l.y| <= 1: capped, axis = axes row 1 (Unity's Cylinder, mesh 10206: radius 0.5, height 2
+ *                     => half_extent = (scale.x / 2, scale.y, scale.z / 2); the mesh is a 20-sided prism, the analytic solid
+ *                     differs from it by <= 0.62 % of the radius)
+ *   VP_OCC_ELLIPSOID  |l|^2 <= 1                                                (Unity's Sphere, mesh 10207: half_extent = scale / 2)
+ * The reference's scene holds two scaled cubes (ground, back wall), two unit cubes and four unit cylinders on the Default layer
+ * (Assets/Volumetric_Particle_System.unity:1755, 5462, 8382, 8623 are the cylinders), all drawn into both depth inputs
+ * (VPR.cs:184 cullingMask = Default, LDM.shader:6-31; RM.shader:14 ZTest against the main camera's depth). */
+#define VP_OCC_BOX       0
+#define VP_OCC_CYLINDER  1
+#define VP_OCC_ELLIPSOID 2
+typedef struct vp_occluder {
+    float   center[3];
+    float   axes[9];              /* rows = the solid's unit axes in world space                   */
+    float   half_extent[3];
+    int32_t type;                 /* VP_OCC_*                                                      */
+} vp_occluder;
+
 #define VP_BRICKS_RGBA16F    0
 #define VP_BRICKS_GREY_ZPAIR 1
 
@@ -308,6 +330,10 @@ int  vp_composite_device(vp_ctx* ctx, const void* d_particles_rgba, void* d_scen
  * position gridCenter - fwd * light_cam_distance, D3D depth (z - near)/(far - near)), and a vp_raymarch* whose params
  * carry no scene_depth renders the eye depth (linear, nearest front face) from them. */
 int  vp_set_occluders(vp_ctx* ctx, const vp_obb* boxes, int32_t n);
+/* ABI 6: the same with typed solids (boxes, capped cylinders, ellipsoids); vp_set_occluders(boxes) == vp_set_occluders2 with
+ * type = VP_OCC_BOX.  Both depth inputs take, per ray, the nearest BACK face under the light camera (Cull Front) and the nearest front
+ * face under the main camera, exactly as for boxes.  An unknown type or a half_extent <= 0 is VP_ERR_BAD_ARG. */
+int  vp_set_occluders2(vp_ctx* ctx, const vp_occluder* solids, int32_t n);
 /* Parity probes: render and read back the two maps. */
 int  vp_render_light_depth(vp_ctx* ctx, float light_near, float light_far, float light_cam_distance, float* out /* [(Ny*nv)][(Nx*nv)] */);
 int  vp_render_scene_depth(vp_ctx* ctx, const vp_camera* cam, float* out /* [H][W] linear eye depth, 3e38 = nothing */);

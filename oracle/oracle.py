@@ -177,9 +177,16 @@ class Oracle:
                  "vpo_raymarch_partial")
         return over, under, mask.value
 
-    def set_occluders(self, boxes):
-        arr = (type(boxes[0]) * len(boxes))(*boxes) if len(boxes) else None
-        self._ck(self.L.vpo_set_occluders(self.h, arr, len(boxes)), "vpo_set_occluders")
+    def set_occluders(self, solids):
+        """vp_obb records (60 B, boxes) or a list holding vp_occluder records (64 B, typed: box / capped cylinder / ellipsoid)."""
+        if all(C.sizeof(b) == 60 for b in solids):
+            arr = (type(solids[0]) * len(solids))(*solids) if len(solids) else None
+            self._ck(self.L.vpo_set_occluders(self.h, arr, len(solids)), "vpo_set_occluders")
+            return
+        buf = (C.c_uint8 * (64 * len(solids)))()                    # vp_occluder = vp_obb + int32 type (0 = box)
+        for i, b in enumerate(solids):
+            C.memmove(C.addressof(buf) + 64 * i, C.byref(b), C.sizeof(b))
+        self._ck(self.L.vpo_set_occluders2(self.h, buf, len(solids)), "vpo_set_occluders2")
 
     def render_light_depth(self, near=0.3, far=1000.0, cam_distance=200.0):
         out = np.empty((self.N[1] * self.nv, self.N[0] * self.nv), dtype=np.float32)

@@ -201,7 +201,7 @@ typedef struct vpo_ctx {
     int filled;
     long samples;
     float* f16lut;               /* 65536 floats */
-    vp_obb* occluders; int n_occluders;
+    vp_occluder* occluders; int n_occluders;
     char err[256];
 } vpo_ctx;
 
@@ -522,11 +522,71 @@ static int ray_obb(const vp_obb* b, v3 o, v3 d, float* t0, float* t1)
     return *t0 <= *t1;
 }
 
+/* Capped cylinder / ellipsoid (ABI 6: the reference scene's four cylinders, scene:1755,5462,8382,8623, are drawn into both depth   */
+/* inputs like every Default-layer mesh, VPR.cs:184, LDM.shader:6-31).  The ray is taken into the solid's normalised local space  */
+/* l = diag(1/h) A (p - c) -- an affine map, so the ray parameter t is unchanged -- where the solid is the unit cylinder about y  */
+/* (x^2 + z^2 <= 1, |y| <= 1) or the unit ball.  The quadric is solved about the ray's point of closest approach to the axis /   */
+/* centre (foot point), not about the far-away origin: with the light camera 200 units out the textbook b^2 - ac loses ~4 digits.*/
+static int ray_quadric(const vp_occluder* b, v3 o, v3 d, float* t0, float* t1)
+{
+    const int cyl = b->type == VP_OCC_CYLINDER;
+    v3 w = v3_sub(o, v3_make(b->center[0], b->center[1], b->center[2]));
+    float p[3], q[3];
+    for (int k = 0; k < 3; ++k) {
+        v3 a = v3_make(b->axes[3 * k], b->axes[3 * k + 1], b->axes[3 * k + 2]);
+        p[k] = v3_dot(a, w) / b->half_extent[k];
+        q[k] = v3_dot(a, d) / b->half_extent[k];
+    }
+    const float qq = cyl ? q[0] * q[0] + q[2] * q[2] : (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    *t0 = -3.0e38f; *t1 = 3.0e38f;
+    if (qq > 0.f) {
+        const float pq = cyl ? p[0] * q[0] + p[2] * q[2] : (p[0] * q[0] + p[1] * q[1]) + p[2] * q[2];
+        const float tc = -(pq / qq);
+        const float f0 = p[0] + tc * q[0], f1 = p[1] + tc * q[1], f2 = p[2] + tc * q[2];
+        const float dist2 = cyl ? f0 * f0 + f2 * f2 : (f0 * f0 + f1 * f1) + f2 * f2;
+        if (dist2 > 1.0f) return 0;
+        const float half = sqrtf((1.0f - dist2) / qq);
+        *t0 = tc - half; *t1 = tc + half;
+    } else {
+        const float dist2 = cyl ? p[0] * p[0] + p[2] * p[2] : (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+        if (dist2 > 1.0f) return 0;
+    }
+    if (cyl) {
+        if (q[1] != 0.f) {
+            const float inv = 1.0f / q[1];
+            const float ta = (-1.0f - p[1]) * inv, tb = (1.0f - p[1]) * inv;
+            *t0 = fmaxf(*t0, fminf(ta, tb));
+            *t1 = fminf(*t1, fmaxf(ta, tb));
+        } else if (p[1] < -1.0f || p[1] > 1.0f) return 0;
+    }
+    return *t0 <= *t1;
+}
+
+static int ray_solid(const vp_occluder* b, v3 o, v3 d, float* t0, float* t1)
+{
+    return b->type == VP_OCC_BOX ? ray_obb((const vp_obb*)b, o, d, t0, t1) : ray_quadric(b, o, d, t0, t1);
+}
+
+VPO_API int vpo_set_occluders2(vpo_ctx* c, const vp_occluder* solids, int n)
+{
+    if (!c || n < 0 || (n > 0 && !solids)) return VP_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (solids[i].type < VP_OCC_BOX || solids[i].type > VP_OCC_ELLIPSOID) return VP_ERR_BAD_ARG;
+        if (solids[i].type != VP_OCC_BOX) for (int k = 0; k < 3; ++k) if (!(solids[i].half_extent[k] > 0.f)) return VP_ERR_BAD_ARG;
+    }
+    free(c->occluders); c->occluders = NULL; c->n_occluders = n;
+    if (n > 0) { c->occluders = (vp_occluder*)malloc((size_t)n * sizeof(vp_occluder)); memcpy(c->occluders, solids, (size_t)n * sizeof(vp_occluder)); }
+    return VP_OK;
+}
+
 VPO_API int vpo_set_occluders(vpo_ctx* c, const vp_obb* boxes, int n)
 {
     if (!c || n < 0 || (n > 0 && !boxes)) return VP_ERR_BAD_ARG;
     free(c->occluders); c->occluders = NULL; c->n_occluders = n;
-    if (n > 0) { c->occluders = (vp_obb*)malloc((size_t)n * sizeof(vp_obb)); memcpy(c->occluders, boxes, (size_t)n * sizeof(vp_obb)); }
+    if (n > 0) {
+        c->occluders = (vp_occluder*)calloc((size_t)n, sizeof(vp_occluder));
+        for (int i = 0; i < n; ++i) { memcpy(&c->occluders[i], &boxes[i], sizeof(vp_obb)); c->occluders[i].type = VP_OCC_BOX; }
+    }
     return VP_OK;
 }
 
@@ -545,7 +605,7 @@ VPO_API int vpo_render_light_depth(vpo_ctx* c, float nearz, float farz, float ca
             float zmin = 3.0e38f;
             for (int i = 0; i < c->n_occluders; ++i) {
                 float t0, t1;
-                if (!ray_obb(&c->occluders[i], o, c->fwd, &t0, &t1)) continue;
+                if (!ray_solid(&c->occluders[i], o, c->fwd, &t0, &t1)) continue;
                 if (t1 >= nearz && t1 <= farz) zmin = fminf(zmin, t1);           /* Cull Front: the back face is drawn */
             }
             out[(size_t)Y * LW + X] = zmin < 3.0e38f ? (zmin - nearz) / (farz - nearz) : 1.0f;
@@ -569,7 +629,7 @@ VPO_API int vpo_render_scene_depth(vpo_ctx* c, const vp_camera* cam, float* out)
             float best = 3.0e38f;
             for (int i = 0; i < c->n_occluders; ++i) {
                 float t0, t1;
-                if (!ray_obb(&c->occluders[i], o, w, &t0, &t1)) continue;
+                if (!ray_solid(&c->occluders[i], o, w, &t0, &t1)) continue;
                 float te = t0 > 0.f ? t0 : t1;
                 float depth = te * (-nit);
                 if (te > 0.f && depth >= cam->near_clip && depth <= farc) best = fminf(best, depth);

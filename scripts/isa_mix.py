@@ -71,7 +71,7 @@ import hashlib
 def kernel_sources_sha():
     h = hashlib.sha256()
     for fn in sorted(os.listdir(CSRC)):
-        if fn in ("fill.hip", "fill_kernels.h", "raymarch.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):
+        if fn in ("fill.hip", "fill_generic.hip", "fill_kernels.h", "raymarch.hip", "raymarch_generic.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):
             h.update(fn.encode() + b"\0" + open(os.path.join(CSRC, fn), "rb").read())
     return h.hexdigest()[:16]
 out = {"method": __doc__.split("usage")[0].strip(), "kernel_sources_sha": kernel_sources_sha(), "kernels": {}}

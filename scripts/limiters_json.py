@@ -10,7 +10,7 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn in ("fill.hip", "fill_kernels.h", "raymarch.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):
+        if fn in ("fill.hip", "fill_generic.hip", "fill_kernels.h", "raymarch.hip", "raymarch_generic.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):
             h.update(fn.encode() + b"\0" + open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
 ctr = {}

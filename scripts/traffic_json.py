@@ -15,7 +15,7 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "volumetric-particles-for-unity_amd", "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn in ("fill.hip", "fill_kernels.h", "raymarch.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):      # the kernels (same fingerprint as bench.py)
+        if fn in ("fill.hip", "fill_generic.hip", "fill_kernels.h", "raymarch.hip", "raymarch_generic.hip", "raymarch_kernels.h", "bin.hip", "vpfx_internal.h"):      # the kernels (same fingerprint as bench.py)
             h.update(fn.encode() + b"\0" + open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
 out = {"kernel_sources_sha": kernel_sources_sha()}

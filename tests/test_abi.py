@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = E.lib()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.vp_abi_version() == abi.VPFX_ABI_VERSION == 5
+    assert lib.vp_abi_version() == abi.VPFX_ABI_VERSION == 6
 
 
 def test_header_constants_match_the_mirror():

@@ -150,3 +150,113 @@ def test_integration_md_snippet_matches_the_header():
 def test_header_prototype_parser_sees_the_whole_abi():
     protos = header_prototypes()
     assert sorted(protos) == sorted(abi.EXPORTED_SYMBOLS)
+
+
+# ---- the C# shim's FRAME vs the Python mirror's (VERDICT r5 missing #2 / next #2) -------------------------------------------------------
+# Nothing compiles C# here, so behaviour is checked statically: both hosts' OnPreRender / OnPostRender are expanded -- helper methods
+# inlined in textual order -- into the sequence of C-ABI calls a synchronous frame can make, and the two sequences must be the same.
+PKG = os.path.join(ROOT, "volumetric-particles-for-unity_amd")
+FRAME_CALLS = {"vp_rebalance", "vp_set_occluders", "vp_set_occluders2", "vp_clear_particles_rt", "vp_set_frame", "vp_bin", "vp_fill", "vp_raymarch",
+               "vp_wait_image", "vp_raymarch_async", "vp_composite_device", "vp_render_light_depth", "vp_render_scene_depth"}
+
+
+def cs_methods(src):
+    """name -> body of every method of the shim (comments stripped, braces matched)."""
+    src = strip_comments(src)
+    out = {}
+    for m in re.finditer(r"\b(?:public\s+|static\s+|private\s+)*(?:void|bool|int|IntPtr|vp_\w+)\s+(\w+)\s*\(([^;{)]*)\)\s*\{", src):
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(src[i], 0)
+            i += 1
+        out[m.group(1)] = src[m.end():i - 1]
+    return out
+
+
+def cs_frame_sequence(methods, entry, skip=("IssueFrameOnRenderThread", "Check")):
+    seq = []
+
+    def expand(name, stack):
+        for m in re.finditer(r"\b(\w+)\s*\(", methods[name]):
+            callee = m.group(1)
+            if callee.startswith("vp_") and callee in FRAME_CALLS:
+                seq.append(callee)
+            elif callee in methods and callee not in skip and callee not in stack:
+                expand(callee, stack + [callee])
+    expand(entry, [entry])
+    return seq
+
+
+def py_frame_sequence(entry):
+    import ast
+    eng = ast.parse(open(os.path.join(PKG, "engine.py")).read())
+    eng_calls = {}
+    for cls in [n for n in eng.body if isinstance(n, ast.ClassDef) and n.name == "Engine"]:
+        for fn in [n for n in cls.body if isinstance(n, ast.FunctionDef)]:
+            calls = [c for c in ast.walk(fn) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute) and c.func.attr.startswith("vp_")]
+            eng_calls[fn.name] = [c.func.attr for c in sorted(calls, key=lambda c: (c.lineno, c.col_offset))]
+    man = ast.parse(open(os.path.join(PKG, "manager.py")).read())
+    cls = [n for n in man.body if isinstance(n, ast.ClassDef) and n.name == "MetavoxelManager"][0]
+    methods = {fn.name: fn for fn in cls.body if isinstance(fn, ast.FunctionDef)}
+    seq = []
+
+    def expand(name, stack):
+        calls = [c for c in ast.walk(methods[name]) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute)]
+        for c in sorted(calls, key=lambda c: (c.lineno, c.col_offset)):
+            f = c.func
+            if isinstance(f.value, ast.Attribute) and f.value.attr == "_engine":                       # self._engine.X(...)
+                seq.extend(v for v in eng_calls.get(f.attr, []) if v in FRAME_CALLS)
+            elif isinstance(f.value, ast.Name) and f.value.id in ("self", "e") and f.attr in methods and f.attr not in stack:
+                expand(f.attr, stack + [f.attr])
+            elif isinstance(f.value, ast.Name) and f.value.id == "e" and f.attr in eng_calls:          # e = self._engine
+                seq.extend(v for v in eng_calls[f.attr] if v in FRAME_CALLS)
+    expand(entry, [entry])
+    return seq
+
+
+def _dedupe(seq):
+    return [c for i, c in enumerate(seq) if i == 0 or c != seq[i - 1]]
+
+
+def test_csharp_frame_makes_the_same_abi_calls_as_the_python_mirror():
+    methods = cs_methods(open(CS).read())
+    for name in ("Start", "OnPreRender", "OnPostRender", "SyncOccluders", "CompositeParticles", "UpdateMetavoxelPositions", "BinParticlesToMetavoxels",
+                 "FillMetavoxels", "RenderMetavoxels", "FillMetavoxel", "RenderMetavoxel", "ClearParticlesRT", "ReadParticlesRT"):
+        assert name in methods, f"the C# shim has no {name}()"
+    cs_post, py_post = _dedupe(cs_frame_sequence(methods, "OnPostRender")), _dedupe(py_frame_sequence("OnPostRender"))
+    expect = ["vp_rebalance", "vp_set_occluders2", "vp_set_frame", "vp_bin", "vp_fill", "vp_raymarch", "vp_wait_image", "vp_raymarch_async"]
+    assert cs_post == expect, cs_post
+    assert py_post == expect, py_post
+    assert _dedupe(cs_frame_sequence(methods, "OnPreRender")) == _dedupe(py_frame_sequence("OnPreRender")) == []   # particlesRT: vp_raymarch starts from 0
+    # the render-thread variant hands the same frame to the library's callback, after syncing the occluders on the idle context
+    rt = _dedupe(cs_frame_sequence(methods, "IssueFrameOnRenderThread", skip=("Check",)))
+    assert rt[:2] == ["vp_rebalance", "vp_set_occluders2"], rt
+
+
+def test_csharp_frame_runs_the_references_callbacks():
+    """VPR.cs:168-177 (OnPreRender: clear + retarget), :184 (light depth map), :204 (scene depth), :210-219 (composite + present)."""
+    methods = cs_methods(open(CS).read())
+    pre = methods["OnPreRender"]
+    assert "GL.Clear(true, true, Color.black)" in pre and "targetTexture = mainSceneRT" in pre and "RenderTexture.active = mainSceneRT" in pre
+    post = methods["OnPostRender"]
+    order = [post.index(x) for x in ("SyncOccluders()", "BinParticlesToMetavoxels()", "FillMetavoxels()", "RenderMetavoxels()", "CompositeParticles()")]
+    assert order == sorted(order), "OnPostRender must run: occluders -> gated bin + fill -> ray-march -> composite"
+    comp = methods["CompositeParticles"]
+    assert "Graphics.Blit(particlesTex, mainSceneRT, matBlendParticles)" in comp and "targetTexture = null" in comp and "Graphics.Blit(mainSceneRT, null" in comp
+    # the two depth inputs are never hard-wired to NULL: they come from the helpers, which return NULL only when the library holds the solids
+    # itself (SceneMeshes -> vp_set_occluders2) or when there is no occlusion at all (None)
+    src = strip_comments(open(CS).read())
+    assert not re.search(r"light_depth_map\s*=\s*IntPtr\.Zero", src) and not re.search(r"scene_depth\s*=\s*IntPtr\.Zero", src)
+    assert re.search(r"light_depth_map\s*=\s*LightDepthMapPtr\(\)", methods["FillParams"])
+    assert re.search(r"scene_depth\s*=\s*SceneDepthPtr\(\)", methods["CameraAndParams"])
+    for helper, handle in (("LightDepthMapPtr", "lightDepthHandle"), ("SceneDepthPtr", "sceneDepthHandle")):
+        body = methods[helper]
+        assert re.search(r"occluderSource\s*==\s*OccluderSource\.UnityDepthTextures\s*&&\s*" + handle + r"\.IsAllocated\s*\?\s*" + handle + r"\.AddrOfPinnedObject\(\)\s*:\s*IntPtr\.Zero", body), helper
+    sync = methods["SyncOccluders"]
+    assert "vp_set_occluders2" in sync and "ReadBackDepthTextures()" in sync and 'LayerMask.NameToLayer("Default")' in sync
+    rb = methods["ReadBackDepthTextures"]
+    assert "RenderWithShader(generateLightDepthMapShader" in rb                      # VPR.cs:184
+    # the solid record the shim marshals is the header's
+    structs = cs_structs(open(CS).read())
+    assert flatten_cs(structs, "vp_occluder") == flatten_ct(abi.vp_occluder)
+    assert C.sizeof(abi.vp_occluder) == 64 and C.sizeof(abi.vp_obb) == 60

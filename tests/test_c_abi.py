@@ -13,7 +13,7 @@ from vpfx_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "volumetric-particles-for-unity_amd")
-STRUCTS = ["vp_config", "vp_particle_layout", "vp_fill_params", "vp_camera", "vp_raymarch_params", "vp_obb", "vp_stats", "vp_multi_info", "vp_xop", "vp_emitter_config"]
+STRUCTS = ["vp_config", "vp_particle_layout", "vp_fill_params", "vp_camera", "vp_raymarch_params", "vp_obb", "vp_occluder", "vp_stats", "vp_multi_info", "vp_xop", "vp_emitter_config"]
 
 
 def _cc(args, **kw):
@@ -69,11 +69,13 @@ def test_demo_scene_from_c_is_the_scene_the_python_binding_renders(tmp_path):
     r = subprocess.run([_build_demo(tmp_path, "demo_scene"), "5", "256", "192"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     nums = {k: float(v) for k, v in re.findall(r"(\w+) (-?[\d.]+)", r.stdout)}
-    sc, em, _ = S.make_demo_scene(width=256, height=192)
+    sc, em, solids = S.make_demo_scene(width=256, height=192)
     em.step(1.0 / 30.0)                                                  # the C loop steps the emitter before frame 0's refill
     parts = em.particles()
     eng = E.Engine(sc.config())
     eng.set_frame(sc.light_to_world, sc.grid_center)
+    eng.set_occluders(solids)                                            # the same eight solids the C file spells out
+    assert abs(nums["light_depth_shadowed"] - int((eng.render_light_depth() < 1).sum())) <= 2
     eng.bin(parts, sc.layout, sc.psys_local_to_world)
     st = eng.stats()
     assert nums["particles"] == len(parts) and nums["occupied_mv"] == st["occupied_mv"] > 0 and nums["pairs"] == st["pairs"]

@@ -168,7 +168,7 @@ def test_bad_arguments_are_refused():
 
 def test_demo_scene_is_fed_by_the_library_emitter():
     sc, em, boxes = S.make_demo_scene(width=64, height=48)
-    assert 50 <= len(sc.particles) <= 60 and len(boxes) == 4
+    assert 50 <= len(sc.particles) <= 60 and len(boxes) == 8      # ground, back, two cubes, four cylinders
     assert sc.particles.tobytes() == em.particles().tobytes()
     again, _, _ = S.make_demo_scene(width=64, height=48)
     assert again.particles.tobytes() == sc.particles.tobytes()

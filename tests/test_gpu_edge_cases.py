@@ -540,6 +540,55 @@ def test_occluder_boxes_produce_both_depth_inputs_on_the_gpu():
     assert ig[..., 3].mean() < 0.9 * E_free_alpha(sc)
 
 
+def test_occluder_cylinders_and_ellipsoids_produce_both_depth_inputs_on_the_gpu():
+    """ABI 6 (VERDICT r5 missing #1): the reference scene's cylinders (scene:1755,5462,8382,8623) -- and spheres -- as analytic solids beside
+    boxes, through vp_set_occluders2: both depth inputs vs the oracle (same fp32 operation order: equal up to silhouette flips), then a whole
+    frame with them."""
+    sc = S.make_scene("T0")
+    L = np.asarray(sc.light_to_world, dtype=np.float64).reshape(4, 4).T
+    R = L[:3, :3]
+    solids = [S.make_solid(abi.VP_OCC_CYLINDER, R[:, 2] * 1.0 + R[:, 0] * 2.5, (1.2, 2.5, 0.8), S.quat_to_matrix((0.3, -0.2, 0.1, 0.927)).T),
+              S.make_solid(abi.VP_OCC_CYLINDER, (-2.0, 0.0, -1.0), (0.5, 1.0, 0.5)),                       # Unity's unit cylinder, axis = world y
+              S.make_solid(abi.VP_OCC_CYLINDER, (1.0, 2.0, 0.0), (0.7, 3.0, 0.7), R.T),                    # axis = light up: rays PARALLEL to nothing special
+              S.make_solid(abi.VP_OCC_CYLINDER, (0.0, 0.0, 3.0), (0.9, 1.5, 0.9), np.roll(R.T, 1, axis=0)),  # axis = light forward: light rays parallel to the axis (qq == 0 branch)
+              S.make_solid(abi.VP_OCC_ELLIPSOID, (2.0, -1.0, 1.0), (1.5, 0.6, 1.0), S.quat_to_matrix((0.1, 0.5, -0.2, 0.837)).T),
+              S.make_box((0.0, -7.0, 0.0), (40.0, 0.5, 40.0))]
+    o, g = O.Oracle(sc.config()), E.Engine(sc.config(), exact=True, early_out=False)
+    for x in (o, g):
+        x.set_frame(sc.light_to_world, sc.grid_center)
+        x.set_occluders(solids)
+    do, dg = o.render_light_depth(), g.render_light_depth()
+    assert (do < 1).mean() > 0.2
+    flips = ((do < 1) != (dg < 1)).sum()
+    assert flips <= 2, flips
+    both_hit = (do < 1) & (dg < 1)
+    np.testing.assert_allclose(dg[both_hit], do[both_hit], rtol=0, atol=2e-7)
+    so, sg = o.render_scene_depth(sc.camera()), g.render_scene_depth(sc.camera())
+    assert ((so < 1e30) == (sg < 1e30)).mean() > 0.9995
+    both_hit = (so < 1e30) & (sg < 1e30)
+    np.testing.assert_allclose(sg[both_hit], so[both_hit], rtol=1e-5)
+    for x in (o, g):
+        x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+        x.fill(sc.fill_params())
+    lo, lg = o.read_lightmap(), g.read_lightmap()
+    close = np.isclose(lg, lo, rtol=1e-5, atol=1e-9)
+    assert (~close).sum() <= 2, (~close).sum()                # a silhouette texel of the depth map may flip a column's shadow index
+    io, ig = o.raymarch(sc.camera(), sc.raymarch_params()), g.raymarch(sc.camera(), sc.raymarch_params())
+    bad = (np.abs(io - ig).max(axis=-1) > 1e-3).sum()
+    assert bad <= 3, bad
+    # typed boxes == vp_obb boxes, bit for bit; bad solids are refused
+    bx = S.make_box((-2.0, 1.0, -1.0), (1.0, 2.0, 1.5), S.quat_to_matrix((0.2, -0.1, 0.3, 0.927)).T)
+    g.set_occluders([bx])
+    d_box = g.render_light_depth()
+    g.set_occluders([S.make_solid(abi.VP_OCC_BOX, (-2.0, 1.0, -1.0), (1.0, 2.0, 1.5), S.quat_to_matrix((0.2, -0.1, 0.3, 0.927)).T)])
+    np.testing.assert_array_equal(g.render_light_depth(), d_box)
+    with pytest.raises(Exception):
+        g.set_occluders([S.make_solid(9, (0, 0, 0), (1, 1, 1))])
+    with pytest.raises(Exception):
+        g.set_occluders([S.make_solid(abi.VP_OCC_ELLIPSOID, (0, 0, 0), (1, -1, 1))])
+    np.testing.assert_array_equal(g.render_light_depth(), d_box)          # a refused call leaves the previous set in place
+
+
 def E_free_alpha(sc):
     g = E.Engine(sc.config())
     g.set_frame(sc.light_to_world, sc.grid_center)
@@ -572,8 +621,8 @@ def test_render_target_emulation_and_debug_views(flag, tol):
 
 
 def test_demo_scene_sequence_with_emitter_and_occluders():
-    """The reference's own scene (10^3 x 32^3 grid, emitter parameters, camera, light, ground/back/cubes) driven frame by
-    frame through MetavoxelManager.OnPostRender; the frame after each refill is checked against the oracle."""
+    """The reference's own scene (10^3 x 32^3 grid, emitter parameters, camera, light, and its eight Default-layer meshes: ground / back /
+    two cubes / four cylinders) driven frame by frame through MetavoxelManager.OnPostRender; the frame after each refill is checked against the oracle."""
     sc, em, boxes = S.make_demo_scene(width=256, height=192)
     m = MetavoxelManager(10, 10, 10, 3.0, 32, 1, sc.width, sc.height)
     m.Start()

@@ -50,7 +50,10 @@ def test_config5_full_size_on_one_gpu():
     torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info()
     if free < 200e9:
-        pytest.skip(f"needs ~190 GB of free HBM for the 64^3 x 64^3 brick pool, {free / 1e9:.0f} GB free")
+        # a 288-GB MI355X with < 200 GB free means something of THIS process (or a stale one) still holds memory: a bug, not an excuse -- fail.
+        # Only a genuinely smaller device may skip.
+        assert total < 250e9, f"config 5 needs ~190 GB of free HBM; only {free / 1e9:.0f} of {total / 1e9:.0f} GB are free on a device that should hold it"
+        pytest.skip(f"device has {total / 1e9:.0f} GB in total: the 64^3 x 64^3 brick pool (~190 GB) cannot fit")
     sc = S.make_scene("C5")
     g = E.Engine(sc.config(), exact=True)
     g.set_frame(sc.light_to_world, sc.grid_center)

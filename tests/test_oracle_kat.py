@@ -223,6 +223,113 @@ def test_occluder_box_scene_depth_is_nearest_front_face():
     np.testing.assert_array_equal(o.raymarch(sc.camera(), sc.raymarch_params()), 0.0)   # everything is behind the wall
 
 
+def _f64_solid_depths(sc, solid, rays_o, rays_d):
+    """Independent float64 restatement: textbook quadratic about the ray origin (the oracle solves about the foot point in fp32).
+    Returns (t_entry, t_exit) per ray, nan where missed."""
+    from vpfx_amd import abi
+    c = np.array(list(solid.center), dtype=np.float64)
+    A = np.array(list(solid.axes), dtype=np.float64).reshape(3, 3)
+    h = np.array(list(solid.half_extent), dtype=np.float64)
+    p = (A @ (rays_o - c).T).T / h
+    q = (A @ rays_d.T).T / h
+    sel = [0, 2] if solid.type == abi.VP_OCC_CYLINDER else [0, 1, 2]
+    a = (q[:, sel] ** 2).sum(1); b = (p[:, sel] * q[:, sel]).sum(1); cc = (p[:, sel] ** 2).sum(1) - 1.0
+    disc = b * b - a * cc
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t0 = np.where(disc >= 0, (-b - np.sqrt(np.abs(disc))) / a, np.nan)
+        t1 = np.where(disc >= 0, (-b + np.sqrt(np.abs(disc))) / a, np.nan)
+        if solid.type == abi.VP_OCC_CYLINDER:
+            ta, tb = (-1 - p[:, 1]) / q[:, 1], (1 - p[:, 1]) / q[:, 1]
+            t0 = np.maximum(t0, np.minimum(ta, tb)); t1 = np.minimum(t1, np.maximum(ta, tb))
+    miss = ~(t0 <= t1)
+    t0[miss] = np.nan; t1[miss] = np.nan
+    return t0, t1
+
+
+@pytest.mark.parametrize("kind", ["cylinder", "ellipsoid"])
+def test_occluder_cylinder_and_ellipsoid_depths_match_a_float64_restatement(kind):
+    """ABI 6 solids (the reference scene's four cylinders, scene:1755,5462,8382,8623): light depth = nearest BACK face (Cull Front,
+    LDM.shader:6), eye depth = nearest front face -- both against an independent float64 ray / quadric intersection."""
+    from vpfx_amd import abi
+    sc = S.make_scene("T0")
+    o = engine(sc)
+    R = _light_axes(sc)
+    rot = S.quat_to_matrix((0.3, -0.2, 0.1, 0.927)).T if kind == "cylinder" else S.quat_to_matrix((0.1, 0.5, -0.2, 0.837)).T
+    typ = abi.VP_OCC_CYLINDER if kind == "cylinder" else abi.VP_OCC_ELLIPSOID
+    solid = S.make_solid(typ, R[:, 2] * 1.0 + R[:, 0] * 0.5, (1.2, 2.5, 0.8), rot)
+    o.set_occluders([solid])
+    d = o.render_light_depth()
+    LH, LW = d.shape
+    N, s = sc.N[0], sc.mv_scale
+    r = N * s * 0.5
+    lx = -r + (np.arange(LW) + 0.5) / LW * 2 * r
+    ly = -r + (np.arange(LH) + 0.5) / LH * 2 * r
+    gx, gy = np.meshgrid(lx, ly)
+    cam = np.asarray(sc.grid_center, dtype=np.float64) - R[:, 2] * 200.0
+    orig = cam + gx.reshape(-1, 1) * R[:, 0] + gy.reshape(-1, 1) * R[:, 1]
+    dirs = np.broadcast_to(R[:, 2], orig.shape)
+    _, t1 = _f64_solid_depths(sc, solid, orig, dirs)
+    expect = np.where(np.isnan(t1), 1.0, (t1 - 0.3) / 999.7).reshape(LH, LW)
+    hit_o, hit_e = d < 1.0, expect < 1.0
+    assert hit_e.mean() > 0.02
+    assert (hit_o != hit_e).sum() <= 4                                       # silhouette texels may flip in fp32
+    both = hit_o & hit_e
+    np.testing.assert_allclose(d[both], expect[both], rtol=0, atol=3e-7)      # 3e-7 of 999.7 world units = 3e-4; fp32 at t ~ 200 has ulp 1.5e-5
+    # eye depth: nearest front face, linear depth = t * (-dir.z) with dir = (x, y, -1/tan(fov/2))
+    sd = o.render_scene_depth(sc.camera())
+    H, W = sd.shape
+    cw = np.asarray(sc.cam_to_world, dtype=np.float64)
+    nit = -1.0 / math.tan(sc.camera().fov_y * 0.5)
+    px = (2 * (np.arange(W) + 0.5) / W - 1) * (W / H)
+    py = 2 * (np.arange(H) + 0.5) / H - 1
+    gx, gy = np.meshgrid(px, py)
+    dc = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, nit)], 1)
+    dw = dc @ cw[:3, :3].T
+    ow = np.broadcast_to(cw[:3, 3], dw.shape)
+    t0, t1 = _f64_solid_depths(sc, solid, ow, dw)
+    te = np.where(t0 > 0, t0, t1)
+    expect = np.where(np.isnan(te) | ~(te > 0), 3.0e38, te * -nit).reshape(H, W)
+    hit_o, hit_e = sd < 1e30, expect < 1e30
+    assert hit_e.mean() > 0.003
+    assert (hit_o != hit_e).sum() <= 6
+    both = hit_o & hit_e
+    np.testing.assert_allclose(sd[both], expect[both], rtol=2e-5)
+
+
+def test_typed_box_equals_vp_obb_and_bad_solids_are_refused():
+    from vpfx_amd import abi
+    sc = S.make_scene("T0")
+    o = engine(sc)
+    R = _light_axes(sc)
+    box = S.make_box(R[:, 2] * 2.0, (3.0, 4.0, 0.25), R.T)
+    o.set_occluders([box])
+    d_box = o.render_light_depth()
+    o.set_occluders([S.make_solid(abi.VP_OCC_BOX, R[:, 2] * 2.0, (3.0, 4.0, 0.25), R.T)])
+    np.testing.assert_array_equal(o.render_light_depth(), d_box)
+    with pytest.raises(Exception):
+        o.set_occluders([S.make_solid(7, (0, 0, 0), (1, 1, 1))])
+    with pytest.raises(Exception):
+        o.set_occluders([S.make_solid(abi.VP_OCC_CYLINDER, (0, 0, 0), (1, 0, 1))])
+
+
+def test_demo_scene_holds_the_reference_scenes_eight_default_layer_meshes():
+    """scene:4703-4760 (ground), 6313-6382 (back), Cube / Cube 1, and the four cylinders at scene:8623, 1755, 8382, 5462 -- all children of 'Scene' at (0,-5,0)."""
+    from vpfx_amd import abi
+    _, _, solids = S.make_demo_scene(width=64, height=48, warm_seconds=0.1)
+    kinds = [b.type for b in solids]
+    assert kinds == [abi.VP_OCC_BOX] * 4 + [abi.VP_OCC_CYLINDER] * 4
+    centers = np.array([list(b.center) for b in solids])
+    np.testing.assert_allclose(centers[4:], [(-8.24, -5, 0), (0, -5, 0), (0, -5, 0), (1.45, -6.05, 9.11)], atol=1e-6)
+    for b in solids[4:]:
+        assert list(b.half_extent) == [0.5, 1.0, 0.5]
+    np.testing.assert_allclose(list(solids[0].half_extent), (25, 0.5, 25))
+    np.testing.assert_allclose(centers[0], (0, -6.52, 0), atol=1e-6)
+    # the back wall: a (50,1,50) cube rotated 90 deg about x: thin along world z, 25 up/down in world y
+    A = np.array(list(solids[1].axes)).reshape(3, 3)
+    np.testing.assert_allclose(np.abs(A.T @ np.array(list(solids[1].half_extent))), (25, 25, 0.5), atol=1e-5)
+    np.testing.assert_allclose(centers[1], (0, 19, 24.5), atol=1e-6)
+
+
 def test_unorm8_emulation_quantises_every_blend():
     from vpfx_amd import abi
     sc = S.make_scene("T0")

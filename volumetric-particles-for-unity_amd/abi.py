@@ -35,7 +35,7 @@ VP_BRICKS_RGBA16F, VP_BRICKS_GREY_ZPAIR = 0, 1
 VP_CUBEMAP_F32 = 0
 VP_CUBEMAP_R8 = 1
 
-VPFX_ABI_VERSION = 5
+VPFX_ABI_VERSION = 6
 
 STATUS_NAMES = {
     0: "VP_OK", -1: "VP_ERR_BAD_ARG", -2: "VP_ERR_HIP", -3: "VP_ERR_OOM",
@@ -165,6 +165,23 @@ class vp_obb(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("axes", C.c_float * 9), ("half_extent", C.c_float * 3)]
 
 
+VP_OCC_BOX, VP_OCC_CYLINDER, VP_OCC_ELLIPSOID = 0, 1, 2
+
+
+class vp_occluder(C.Structure):
+    """ABI 6: typed occluder solid; the first 60 bytes are a vp_obb."""
+    _fields_ = [("center", C.c_float * 3), ("axes", C.c_float * 9), ("half_extent", C.c_float * 3), ("type", C.c_int32)]
+
+
+def as_occluders(solids):
+    """A ctypes array of vp_occluder from a mixed list of vp_obb (-> VP_OCC_BOX) and vp_occluder records."""
+    arr = (vp_occluder * len(solids))()
+    for i, b in enumerate(solids):
+        C.memmove(C.byref(arr[i]), C.byref(b), C.sizeof(vp_obb))
+        arr[i].type = b.type if isinstance(b, vp_occluder) else VP_OCC_BOX
+    return arr
+
+
 class vp_emitter_config(C.Structure):
     """Parameters of the library's particle source (the demo scene's ParticleSystem, scene:2264-2620)."""
     _fields_ = [("seed", C.c_uint64), ("rate", C.c_float), ("lifetime", C.c_float), ("speed", C.c_float), ("size", C.c_float),
@@ -211,7 +228,7 @@ EXPORTED_SYMBOLS = [
     "vp_raymarch", "vp_raymarch_device", "vp_raymarch_async", "vp_wait_image", "vp_clear_particles_rt", "vp_render_metavoxel", "vp_read_particles_rt", "vp_composite_device",
     "vp_fill_local", "vp_fill_finish", "vp_fill_finish_gathered", "vp_raymarch_partial_device", "vp_blend_partials_device",
     "vp_blend_partials_range_device",
-    "vp_z_boundary", "vp_z_histogram", "vp_set_occluders", "vp_render_light_depth", "vp_render_scene_depth",
+    "vp_z_boundary", "vp_z_histogram", "vp_set_occluders", "vp_set_occluders2", "vp_render_light_depth", "vp_render_scene_depth",
     "vp_get_mv_positions", "vp_read_binlist", "vp_read_bincounts", "vp_read_brick",
     "vp_read_lightmap", "vp_get_stats", "vp_last_kernel_ms",
     "vp_raymarch_partial_handoff_device", "vp_read_zsamples",

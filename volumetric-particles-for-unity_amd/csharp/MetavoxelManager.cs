@@ -13,7 +13,15 @@
 //   RenderMetavoxels()           VPR.cs:637-713   -> vp_raymarch (no per-MV DrawMeshNow / ROP blend)
 //   RenderMetavoxel(xx,yy,zz,i)  VPR.cs:766-794   -> vp_render_metavoxel (one metavoxel blended into the library's particlesRT)
 //   UpdateMetavoxelPositions()   VPR.cs:370-394   -> vp_set_frame
+// and what it keeps of the reference's frame around them (VPR.cs:168-220), so that the component is a drop-in for the whole callback pair:
+//   OnPreRender                  VPR.cs:168-177   clear mainSceneRT, retarget the camera to it (particlesRT: cleared by vp_raymarch itself)
+//   light depth map              VPR.cs:184, 320-367 -> SyncOccluders (vp_set_occluders2: the library renders the map inside vp_fill), or the
+//                                                    light camera's depth read back and passed as vp_fill_params.light_depth_map
+//   ZTest vs the scene depth     VPR.cs:204       -> the same solids (the library renders the eye depth), or _CameraDepthTexture read back
+//                                                    and passed as vp_raymarch_params.scene_depth
+//   composite + present          VPR.cs:210-219   -> Graphics.Blit(particlesTex, mainSceneRT, matBlendParticles); Blit to the back buffer
 using System;
+using System.Collections.Generic;
 using System.Runtime.InteropServices;
 using UnityEngine;
 
@@ -38,7 +46,20 @@ namespace MetavoxelEngine
         public bool fadeOutParticles = false;
         public float opacityFactor = 0.04f;
         public int softParticleStepDistance = 20;
+        public Material matBlendParticles;         // VPR.cs:77: the reference's CompositeParticles material (Blend One OneMinusSrcAlpha, One One)
+        public Shader generateLightDepthMapShader; // VPR.cs:79 (used with OccluderSource.UnityDepthTextures only)
         // ---- added by this binding ---------------------------------------------------------------------------
+        public enum OccluderSource
+        {
+            None,                // no scene occlusion: light depth 1.0 everywhere, no ZTest (the synthetic benchmark configs)
+            SceneMeshes,         // every enabled MeshRenderer on the Default layer (lightCamera.cullingMask, VPR.cs:346) whose mesh is Unity's
+                                 // Cube / Cylinder / Sphere goes to the library as an analytic solid (vp_set_occluders2); the library renders
+                                 // BOTH depth inputs on the GPU -- nothing is read back from Unity.  The reference's scene is 4 cubes + 4 cylinders
+            UnityDepthTextures   // the reference's own way: lightCamera.RenderWithShader (VPR.cs:184) and the main camera's depth texture
+                                 // (VPR.cs:152, 204), both read back through `copyDepthMaterial` and passed as pointers
+        }
+        public OccluderSource occluderSource = OccluderSource.SceneMeshes;
+        public Material copyDepthMaterial;         // UnityDepthTextures: csharp/VpfxCopyDepth.shader (pass 0: raw depth, pass 1: linear eye depth)
         public int[] gpuDevices = new int[0];      // HIP ordinals; empty / one entry = one GPU.  N entries: the library cuts the grid into N
                                                    // light-axis slabs, one per GPU, with RCCL inside (vp_config.num_devices / devices[])
         public int rebalanceInterval = 240;        // multi-GPU: frames between vp_rebalance calls (0 = never re-cut the slabs)
@@ -87,6 +108,15 @@ namespace MetavoxelEngine
         }
 
         [StructLayout(LayoutKind.Sequential)]
+        struct vp_occluder                     // ABI 6: typed occluder solid (0 box, 1 capped cylinder about its local y, 2 ellipsoid)
+        {
+            public float cx, cy, cz;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public float[] axes;
+            public float hx, hy, hz;
+            public int type;
+        }
+
+        [StructLayout(LayoutKind.Sequential)]
         struct vp_unity_frame                  // one frame for the render-thread callback (include/vpfx.h "Unity native-plugin hookup")
         {
             public IntPtr ctx; public int flags, particle_count;
@@ -116,6 +146,7 @@ namespace MetavoxelEngine
         [DllImport(LIB)] static extern int vp_pin_host_buffer(IntPtr ctx, IntPtr ptr, ulong bytes);
         [DllImport(LIB)] static extern int vp_unpin_host_buffer(IntPtr ctx, IntPtr ptr);
         [DllImport(LIB)] static extern int vp_rebalance(IntPtr ctx);
+        [DllImport(LIB)] static extern int vp_set_occluders2(IntPtr ctx, IntPtr solids, int n);   // IntPtr: an array of vp_occluder marshalled by hand (ByValArray members)
         [DllImport(LIB)] static extern IntPtr vp_unity_render_event_func();
         [DllImport(LIB)] static extern int vp_unity_set_frame_desc(int slot, ref vp_unity_frame frame);
         [DllImport(LIB)] static extern int vp_unity_register_output(int slot, IntPtr dRgbaOut, IntPtr hRgbaOut);
@@ -135,6 +166,13 @@ namespace MetavoxelEngine
         Texture2D particlesTex;
         Quaternion lightOrientation;
         Vector3 wsGridCenter;
+        RenderTexture mainSceneRT;     // VPR.cs:110, 236-244: the camera draws the opaque scene into this; its depth is what the ray-march is tested against
+        RenderTexture lightDepthMap;   // VPR.cs:116, 275-281 (UnityDepthTextures only)
+        GameObject lightCamera;        // VPR.cs:119, 320-367 (UnityDepthTextures only)
+        float[] lightDepth, sceneDepth;            // read-back copies handed to the library (UnityDepthTextures only)
+        GCHandle lightDepthHandle, sceneDepthHandle;
+        Texture2D lightDepthTex, sceneDepthTex;
+        int occluderHash = 0; bool occludersSent = false;
 
         static float[] ToArray(Matrix4x4 m)   // Unity Matrix4x4 is column-major in memory: m00,m10,m20,m30,m01,...
         {
@@ -181,6 +219,55 @@ namespace MetavoxelEngine
             lightOrientation = dirLight.transform.rotation;
             wsGridCenter = gridCenter.transform.position;
             UpdateMetavoxelPositions();
+            CreateSceneTargets();
+        }
+
+        // mainSceneRT (VPR.cs:236-244) and, for OccluderSource.UnityDepthTextures, lightDepthMap + the camera at the light (VPR.cs:275-281, 320-367)
+        void CreateSceneTargets()
+        {
+            Camera cam = GetComponent<Camera>();
+            mainSceneRT = new RenderTexture(Screen.width, Screen.height, 24, RenderTextureFormat.ARGB32);
+            mainSceneRT.Create();
+            cam.targetTexture = mainSceneRT;
+            if (occluderSource != OccluderSource.UnityDepthTextures) return;
+            cam.depthTextureMode = DepthTextureMode.Depth;                 // VPR.cs:152: _CameraDepthTexture
+            int lw = numMetavoxelsX * numVoxelsInMetavoxel, lh = numMetavoxelsY * numVoxelsInMetavoxel;
+            lightDepthMap = new RenderTexture(lw, lh, 24, RenderTextureFormat.Depth);
+            lightDepthMap.Create();
+            lightCamera = new GameObject("LightCamera");
+            lightCamera.transform.parent = dirLight.transform;
+            lightCamera.SetActive(false);
+            Camera lc = lightCamera.AddComponent<Camera>();
+            float r = numMetavoxelsX * mvScale.x * 0.5f, t = numMetavoxelsY * mvScale.y * 0.5f;
+            lc.orthographic = true;
+            lc.projectionMatrix = Matrix4x4.Ortho(-r, r, -t, t, 0.3f, 1000f);                  // tight fit to the grid, VPR.cs:338-342
+            lc.targetTexture = lightDepthMap;
+            lc.cullingMask = 1 << LayerMask.NameToLayer("Default");
+            lc.clearFlags = CameraClearFlags.Depth | CameraClearFlags.Color;
+            lc.useOcclusionCulling = false;
+            PlaceLightCamera();
+            lightDepth = new float[lw * lh]; sceneDepth = new float[Screen.width * Screen.height];
+            lightDepthHandle = GCHandle.Alloc(lightDepth, GCHandleType.Pinned);
+            sceneDepthHandle = GCHandle.Alloc(sceneDepth, GCHandleType.Pinned);
+            lightDepthTex = new Texture2D(lw, lh, TextureFormat.RFloat, false);
+            sceneDepthTex = new Texture2D(Screen.width, Screen.height, TextureFormat.RFloat, false);
+        }
+
+        void PlaceLightCamera()                                            // UpdatePositionOfCameraAtLight, VPR.cs:361-367
+        {
+            if (lightCamera == null) return;
+            lightCamera.transform.position = wsGridCenter - dirLight.transform.forward * 200f;
+            lightCamera.transform.localRotation = Quaternion.identity;
+        }
+
+        void OnPreRender()                                                 // VPR.cs:168-177
+        {
+            // particlesRT lives in the library: vp_raymarch starts from dst = 0 (what GL.Clear(false, true, (0,0,0,0)) does at VPR.cs:171-172);
+            // the per-metavoxel path clears it with ClearParticlesRT().  mainSceneRT is Unity's: clear it and make the camera draw into it.
+            if (mainSceneRT == null) return;
+            RenderTexture.active = mainSceneRT;
+            GL.Clear(true, true, Color.black);
+            GetComponent<Camera>().targetTexture = mainSceneRT;
         }
 
         void OnDestroy()
@@ -192,6 +279,8 @@ namespace MetavoxelEngine
             if (rgbaHandle.IsAllocated) { vp_unpin_host_buffer(ctx, rgbaHandle.AddrOfPinnedObject()); rgbaHandle.Free(); }
             if (partsHandle.IsAllocated) partsHandle.Free();
             if (cubeHandle.IsAllocated) cubeHandle.Free();
+            if (lightDepthHandle.IsAllocated) lightDepthHandle.Free();
+            if (sceneDepthHandle.IsAllocated) sceneDepthHandle.Free();
             vp_destroy(ctx); ctx = IntPtr.Zero;
         }
 
@@ -200,6 +289,8 @@ namespace MetavoxelEngine
             if (ctx == IntPtr.Zero) return;
             if (useRenderThread) { IssueFrameOnRenderThread(); return; }
             if (gpuDevices.Length > 1 && rebalanceInterval > 0 && Time.frameCount % rebalanceInterval == 0) vp_rebalance(ctx);
+            // the light's view of the opaque scene (VPR.cs:184): the solids themselves (the library renders the map inside vp_fill), or Unity's render read back
+            SyncOccluders();
             // the very first call always bins + fills: ray-marching before any fill is VP_ERR_STATE
             if (Time.frameCount % updateInterval == 0 || !filledOnce)
             {
@@ -208,13 +299,95 @@ namespace MetavoxelEngine
                     lightOrientation = dirLight.transform.rotation;
                     wsGridCenter = gridCenter.transform.position;
                     UpdateMetavoxelPositions();
+                    PlaceLightCamera();
                 }
                 BinParticlesToMetavoxels();
                 FillMetavoxels();
             }
+            // depth-tested against the opaque scene's depth (VPR.cs:204), result in particlesTex
             RenderMetavoxels();
-            // particlesTex now holds the ray-marched volume; composite it exactly as the reference does (VPR.cs:210,
-            // CompositeParticles.shader: Blend One OneMinusSrcAlpha, One One).
+            CompositeParticles();
+        }
+
+        // Blend the particles onto the opaque scene and present (VPR.cs:210, 216-219; CompositeParticles.shader:10 -- the reference's own material).
+        void CompositeParticles()
+        {
+            if (mainSceneRT == null) return;
+            if (matBlendParticles != null) Graphics.Blit(particlesTex, mainSceneRT, matBlendParticles);
+            GetComponent<Camera>().targetTexture = null;                   // else the Blit to the back buffer does not work (VPR.cs:218)
+            Graphics.Blit(mainSceneRT, null as RenderTexture);
+        }
+
+        // The opaque scene as the library sees it.  SceneMeshes: collect the Default-layer primitives and hand them over when something moved.
+        // UnityDepthTextures: render the light's depth map the reference's way (VPR.cs:184) and read both depth textures back.
+        void SyncOccluders()
+        {
+            if (occluderSource == OccluderSource.None) return;
+            if (occluderSource == OccluderSource.UnityDepthTextures) { ReadBackDepthTextures(); return; }
+            var solids = new List<vp_occluder>();
+            int hash = 17;
+            int defaultLayer = LayerMask.NameToLayer("Default");
+            foreach (MeshRenderer mr in FindObjectsOfType<MeshRenderer>())
+            {
+                if (!mr.enabled || mr.gameObject.layer != defaultLayer) continue;
+                MeshFilter mf = mr.GetComponent<MeshFilter>();
+                if (mf == null || mf.sharedMesh == null) continue;
+                int type;
+                string mesh = mf.sharedMesh.name;
+                if (mesh == "Cube") type = 0; else if (mesh == "Cylinder") type = 1; else if (mesh == "Sphere") type = 2;
+                else continue;                                             // other meshes: use OccluderSource.UnityDepthTextures
+                Transform t = mr.transform;
+                Vector3 c = t.position, sc = t.lossyScale, ax = t.right, ay = t.up, az = t.forward;
+                // Unity's primitives: Cube spans [-0.5, 0.5]^3; Cylinder: radius 0.5, height 2 about local y; Sphere: radius 0.5
+                var o = new vp_occluder { cx = c.x, cy = c.y, cz = c.z, axes = new float[] { ax.x, ax.y, ax.z, ay.x, ay.y, ay.z, az.x, az.y, az.z },
+                                          hx = 0.5f * Mathf.Abs(sc.x), hy = (type == 1 ? 1.0f : 0.5f) * Mathf.Abs(sc.y), hz = 0.5f * Mathf.Abs(sc.z), type = type };
+                solids.Add(o);
+                hash = hash * 31 + c.GetHashCode(); hash = hash * 31 + t.rotation.GetHashCode(); hash = hash * 31 + sc.GetHashCode(); hash = hash * 31 + type;
+            }
+            if (occludersSent && hash == occluderHash) return;             // nothing moved: the solids in the context are current
+            int size = Marshal.SizeOf(typeof(vp_occluder));                // 64
+            IntPtr buf = Marshal.AllocHGlobal(Math.Max(1, solids.Count) * size);
+            try
+            {
+                for (int i = 0; i < solids.Count; i++) Marshal.StructureToPtr(solids[i], new IntPtr(buf.ToInt64() + (long)i * size), false);
+                if (Check(vp_set_occluders2(ctx, solids.Count > 0 ? buf : IntPtr.Zero, solids.Count), "vp_set_occluders2")) { occluderHash = hash; occludersSent = true; }
+            }
+            finally { Marshal.FreeHGlobal(buf); }
+        }
+
+        // OccluderSource.UnityDepthTextures: the two depth inputs exactly as the reference produces them, copied to host arrays.
+        //   light: lightCamera.RenderWithShader(generateLightDepthMapShader) -> lightDepthMap (D3D ortho depth, VPR.cs:184; Fill.shader:217-218 reads it raw)
+        //   eye:   _CameraDepthTexture -> linear eye depth (what RM.shader:14's ZTest compares after projection)
+        // row 0 of both arrays = bottom row of the view (Texture2D.ReadPixels' order = the library's image order).
+        void ReadBackDepthTextures()
+        {
+            if (lightCamera == null || copyDepthMaterial == null) return;
+            lightCamera.GetComponent<Camera>().RenderWithShader(generateLightDepthMapShader, null as string);
+            ReadDepth(lightDepthMap, lightDepthTex, lightDepth, 0);
+            ReadDepth(null, sceneDepthTex, sceneDepth, 1);                 // pass 1 samples _CameraDepthTexture itself
+        }
+
+        void ReadDepth(RenderTexture src, Texture2D staging, float[] dst, int pass)
+        {
+            RenderTexture tmp = RenderTexture.GetTemporary(staging.width, staging.height, 0, RenderTextureFormat.RFloat);
+            Graphics.Blit(src, tmp, copyDepthMaterial, pass);
+            RenderTexture.active = tmp;
+            staging.ReadPixels(new Rect(0, 0, staging.width, staging.height), 0, 0, false);
+            RenderTexture.active = null;
+            RenderTexture.ReleaseTemporary(tmp);
+            Color[] px = staging.GetPixels();
+            for (int i = 0; i < dst.Length; i++) dst[i] = px[i].r;
+        }
+
+        // what goes into vp_fill_params.light_depth_map / vp_raymarch_params.scene_depth: NULL means "the library renders it from the solids it
+        // holds" (SceneMeshes) or "no occlusion" (None); with UnityDepthTextures it is the read-back copy -- never NULL once the targets exist
+        IntPtr LightDepthMapPtr()
+        {
+            return occluderSource == OccluderSource.UnityDepthTextures && lightDepthHandle.IsAllocated ? lightDepthHandle.AddrOfPinnedObject() : IntPtr.Zero;
+        }
+        IntPtr SceneDepthPtr()
+        {
+            return occluderSource == OccluderSource.UnityDepthTextures && sceneDepthHandle.IsAllocated ? sceneDepthHandle.AddrOfPinnedObject() : IntPtr.Zero;
         }
 
         // The same frame from Unity's render thread: describe it, GL.IssuePluginEvent, pick the result up next frame (the callback runs
@@ -227,9 +400,11 @@ namespace MetavoxelEngine
             // completion handshake: the event issued last frame reads `parts` (vp_bin) and writes `rgba` (read-back) whenever the render thread
             // gets to it.  Until the library has counted it (events_run == issued) neither array may be touched and nothing else may run on the
             // context: skip this frame's issue and show the previous texture.
-            if (done < issuedEvents) return;
+            if (done < issuedEvents) { CompositeParticles(); return; }      // still present the opaque scene + the previous particles
             if (done > 0) { Check(last, "render-thread frame"); if (last == 0) { filledOnce = true; cubemapResident = true; particlesTex.SetPixelData(rgba, 0); particlesTex.Apply(false); } }
             if (gpuDevices.Length > 1 && rebalanceInterval > 0 && Time.frameCount % rebalanceInterval == 0) vp_rebalance(ctx);   // no event in flight here
+            SyncOccluders();                                               // likewise: the context is idle between events
+            CompositeParticles();                                          // the image picked up above, over this frame's opaque scene
             bool refill = Time.frameCount % updateInterval == 0 || !filledOnce;
             bool moved = dirLight.transform.rotation != lightOrientation || wsGridCenter != gridCenter.transform.position || !filledOnce;
             if (moved) { lightOrientation = dirLight.transform.rotation; wsGridCenter = gridCenter.transform.position; }
@@ -284,7 +459,7 @@ namespace MetavoxelEngine
                 ambient_r = ambientColor.x, ambient_g = ambientColor.y, ambient_b = ambientColor.z, init_light_intensity = 1.0f,
                 light_near = 0.3f, light_far = 1000f, light_cam_distance = 200f, cubemap_size = displacementTexture.width,
                 cubemap_format = 1 /* VP_CUBEMAP_R8 */,
-                cubemap = IntPtr.Zero, light_depth_map = IntPtr.Zero /* no occluders; pass the light depth map here when rendered */ };
+                cubemap = IntPtr.Zero, light_depth_map = LightDepthMapPtr() };
         }
 
         void FillMetavoxels()                                              // VPR.cs:495-520
@@ -325,7 +500,7 @@ namespace MetavoxelEngine
                 world_to_camera = ToArray(c.worldToCameraMatrix), camera_to_world = ToArray(c.cameraToWorldMatrix),
                 px = cp.x, py = cp.y, pz = cp.z, fov_y = Mathf.Deg2Rad * c.fieldOfView, near_clip = c.nearClipPlane, far_clip = c.farClipPlane };
             rp = new vp_raymarch_params { steps_per_mv = rayMarchSteps, soft_distance = softParticleStepDistance,
-                                          scene_depth = IntPtr.Zero, flags = bShowMetavoxelDrawOrder ? 8 : 0, reserved = new int[3] };
+                                          scene_depth = SceneDepthPtr(), flags = bShowMetavoxelDrawOrder ? 8 : 0, reserved = new int[3] };
         }
 
         public void RenderMetavoxels()                                     // VPR.cs:637-713
@@ -333,15 +508,16 @@ namespace MetavoxelEngine
             if (!filledOnce) return;                                       // nothing filled yet: nothing to march
             vp_camera cam; vp_raymarch_params rp;
             CameraAndParams(out cam, out rp);
-            if (asyncReadback) {
-                // last frame's image has had a whole frame to land in `rgba`: show it, then queue this frame's march + copy
-                if (imageInFlight && Check(vp_wait_image(ctx), "vp_wait_image")) { particlesTex.SetPixelData(rgba, 0); particlesTex.Apply(false); }
-                imageInFlight = Check(vp_raymarch_async(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch_async");
+            if (!asyncReadback)
+            {
+                Check(vp_raymarch(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch");
+                particlesTex.SetPixelData(rgba, 0);
+                particlesTex.Apply(false);
                 return;
             }
-            Check(vp_raymarch(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch");
-            particlesTex.SetPixelData(rgba, 0);
-            particlesTex.Apply(false);
+            // last frame's image has had a whole frame to land in `rgba`: show it, then queue this frame's march + copy
+            if (imageInFlight && Check(vp_wait_image(ctx), "vp_wait_image")) { particlesTex.SetPixelData(rgba, 0); particlesTex.Apply(false); }
+            imageInFlight = Check(vp_raymarch_async(ctx, ref cam, ref rp, rgbaHandle.AddrOfPinnedObject()), "vp_raymarch_async");
         }
         bool imageInFlight = false;
 

@@ -806,24 +806,42 @@ VP_EXPORT int vp_z_boundary(vp_ctx* c, const vp_camera* cam, int32_t* zb)
 }
 
 // ---- scene occluders -----------------------------------------------------------------------------------
-VP_EXPORT int vp_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n)
+VP_EXPORT int vp_set_occluders2(vp_ctx* c, const vp_occluder* solids, int32_t n)
 {
     if (!c) return VP_ERR_BAD_ARG;
-    if (n < 0 || (n > 0 && !boxes)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders: bad argument");
-    if (c->multi) return multi_set_occluders(c, boxes, n);
+    if (n < 0 || (n > 0 && !solids)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders2: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (solids[i].type < VP_OCC_BOX || solids[i].type > VP_OCC_ELLIPSOID) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders2: unknown solid type");
+        if (solids[i].type != VP_OCC_BOX)                              // boxes keep ABI 5's behaviour (a flat box is a plane)
+            for (int k = 0; k < 3; ++k)
+                if (!(solids[i].half_extent[k] > 0.f)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders2: half_extent must be > 0");
+    }
+    if (c->multi) return multi_set_occluders(c, solids, n);
     int rc = ensure_device(c); if (rc) return rc;
     if (n > c->occluders_cap) {
         if (c->d_occluders) VP_HIP(hipFree(c->d_occluders));
         c->d_occluders = nullptr; c->occluders_cap = 0;
-        VP_HIP(hipMalloc((void**)&c->d_occluders, (size_t)(n + 8) * sizeof(vp_obb)));
+        VP_HIP(hipMalloc((void**)&c->d_occluders, (size_t)(n + 8) * sizeof(vp_occluder)));
         c->occluders_cap = n + 8;
     }
     if (n > 0) {
-        VP_HIP(hipMemcpyAsync(c->d_occluders, boxes, (size_t)n * sizeof(vp_obb), hipMemcpyHostToDevice, c->stream));
+        VP_HIP(hipMemcpyAsync(c->d_occluders, solids, (size_t)n * sizeof(vp_occluder), hipMemcpyHostToDevice, c->stream));
         { int rcs = stream_sync(c); if (rcs) return rcs; }
     }
     c->n_occluders = n;
     return VP_OK;
+}
+
+VP_EXPORT int vp_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n)
+{
+    if (!c) return VP_ERR_BAD_ARG;
+    if (n < 0 || (n > 0 && !boxes)) return vp_fail(c, VP_ERR_BAD_ARG, "vp_set_occluders: bad argument");
+    vp_occluder* v = n ? (vp_occluder*)calloc((size_t)n, sizeof(vp_occluder)) : nullptr;
+    if (n && !v) return vp_fail(c, VP_ERR_OOM, "vp_set_occluders: out of host memory");
+    for (int i = 0; i < n; ++i) { memcpy(&v[i], &boxes[i], sizeof(vp_obb)); v[i].type = VP_OCC_BOX; }
+    const int rc = vp_set_occluders2(c, v, n);
+    free(v);
+    return rc;
 }
 
 VP_EXPORT int vp_render_light_depth(vp_ctx* c, float light_near, float light_far, float light_cam_distance, float* out)

@@ -75,7 +75,8 @@ VP_EMIT_API int vp_emitter_create(const vp_emitter_config* cfg, vp_emitter** out
 {
     if (!cfg || !out) return VP_ERR_BAD_ARG;
     *out = nullptr;
-    if (!(cfg->rate >= 0.f) || !(cfg->lifetime > 0.f) || !(cfg->cone_radius > 0.f) || !(cfg->cone_angle_deg >= 0.f && cfg->cone_angle_deg < 90.f) ||
+    // lifetime: finite and <= 1e5 s (the prewarm below simulates lifetime x 30 steps: +inf / 1e30 would be an endless loop or a UB cast)
+    if (!(cfg->rate >= 0.f) || !std::isfinite(cfg->rate) || !(cfg->lifetime > 0.f) || !(cfg->lifetime <= 1.0e5f) || !(cfg->cone_radius > 0.f) || !(cfg->cone_angle_deg >= 0.f && cfg->cone_angle_deg < 90.f) ||
         !(cfg->size > 0.f) || !std::isfinite(cfg->speed) || !std::isfinite(cfg->angular_velocity_deg) || cfg->max_particles < 0 ||
         cfg->max_particles > (1 << 24))
         return VP_ERR_BAD_ARG;

@@ -81,12 +81,22 @@ struct Rccl {
         const char* forced = getenv("VPFX_RCCL_LIBRARY");
         if (forced && *forced) {
             so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-            if (!so) { err = std::string("VPFX_RCCL_LIBRARY=") + forced + " cannot be loaded (" + (dlerror() ? dlerror() : "?") + ")"; return false; }
+            if (!so) {                                                  // dlerror() clears its state: ONE call per failure
+                const char* de = dlerror();
+                err = std::string("VPFX_RCCL_LIBRARY=") + forced + " cannot be loaded (" + (de ? de : "?") + ")";
+                return false;
+            }
         } else {
             const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-            for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+            std::string why;
+            for (const char* n : names) {
+                so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (so) break;
+                const char* de = dlerror();                                // once, straight after the failing dlopen
+                why = de ? de : "?";
+            }
+            if (!so) { err = "librccl.so.1 not found (" + why + ")"; return false; }
         }
-        if (!so) { err = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")"; return false; }
         bool ok = true;
         auto sym = [&](auto& fn, const char* name) {
             fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(so, name));
@@ -128,11 +138,15 @@ struct Kid {
     hipEvent_t ev_local = nullptr, ev_tau = nullptr;      // local fill pass done (compute stream) / transmittance maps gathered (exchange stream)
     bool tau_pending = false;                             // ev_tau recorded and not yet waited for by the compute stream
     ncclComm_t comm = nullptr;
-    // Guards `comm` against the one cross-thread access there is: multi_abort (any thread) takes the communicator away and ncclCommAbort()s it
-    // -- which frees it -- while this rank's own thread may be about to hand it to ncclSend / ncclRecv / ncclAllGather / ncclCommGetAsyncError.
-    // The owner holds the mutex across each RCCL call (they only enqueue work: microseconds); the aborting thread try-locks with a deadline and,
-    // failing that, leaves the communicator to its owner, which sees the abort flag when the call returns (free_kid destroys it then).
-    std::unique_ptr<std::timed_mutex> comm_m{new std::timed_mutex()};
+    // `comm` is touched by two threads: its owner (this rank's thread: ncclSend / ncclRecv / ncclAllGather / ncclCommGetAsyncError) and whoever
+    // aborts the context (multi_abort, any thread: takes the communicator away and ncclCommAbort()s it, which frees it).  The gate's mutex is
+    // held only to hand the pointer over -- NEVER across an RCCL call, which can block for ever (lazy connection set-up waiting for a dead peer,
+    // an in-process collective waiting for a peer thread that already failed).  The owner marks itself "inside a call" and works on
+    // a local copy of the handle; the aborting thread waits up to 200 ms for the call to return (the clean case: calls only enqueue work) and
+    // otherwise aborts UNDER the blocked call -- what ncclCommAbort exists for (it makes the blocked call return); the owner drops its copy when
+    // it comes back and never destroys it.  Every communicator of an aborted context is therefore aborted, by the aborter or (free_kid) its owner.
+    struct CommGate { std::mutex m; std::condition_variable cv; bool in_call = false; };
+    std::unique_ptr<CommGate> gate{new CommGate()};
     float* d_tau_all = nullptr;       // [world][LH][LW]: all-gathered slab transmittance maps (own slot written by the local fill pass)
     float* d_img[2] = {nullptr, nullptr};   // partial images of the slab (phase-A composite, phase-B composite), padded to whole pieces
     uint8_t* d_tmaps = nullptr;       // [world][H][W] received hand-off maps of the slabs in front (one byte per pixel, RmHandoff)
@@ -199,6 +213,20 @@ namespace {
 
 Kid* local_kid(vp_multi* M, int rank) { return (rank >= M->first_rank && rank < M->first_rank + M->nlocal) ? &M->kids[rank - M->first_rank] : nullptr; }
 
+// Owner side of Kid::gate: take a local copy of the communicator for ONE RCCL call sequence (nullptr: aborted / taken away) ...
+ncclComm_t comm_enter(vp_multi* M, Kid& k)
+{
+    std::lock_guard<std::mutex> lk(k.gate->m);
+    if (!k.comm || M->aborted.load()) return nullptr;
+    k.gate->in_call = true;
+    return k.comm;
+}
+// ... and give the gate back when the calls have returned (RAII: every exit path of the caller)
+struct CommLeave {
+    Kid& k;
+    ~CommLeave() { { std::lock_guard<std::mutex> lk(k.gate->m); k.gate->in_call = false; } k.gate->cv.notify_all(); }
+};
+
 void multi_abort(vp_multi* M, int rank, const std::string& why)
 {
     int expected = 0;
@@ -207,10 +235,15 @@ void multi_abort(vp_multi* M, int rank, const std::string& why)
     fprintf(stderr, "[libvpfx] fan-out aborted by rank %d: %s\n", rank, why.c_str());
     if (M->use_rccl && rccl().CommAbort)
         for (Kid& k : M->kids) {
-            // ends the kernels of stuck collectives and frees the communicator -- under the kid's lock (see Kid::comm_m)
-            std::unique_lock<std::timed_mutex> lk(*k.comm_m, std::chrono::milliseconds(200));
-            if (!lk.owns_lock()) continue;                   // its owner is inside an RCCL call right now: it finds the abort flag on return
-            if (k.comm) { ncclComm_t cm = k.comm; k.comm = nullptr; (void)rccl().CommAbort(cm); }
+            ncclComm_t cm = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(k.gate->m);
+                // the owner is inside an RCCL call: give it 200 ms to come back (calls only enqueue work); if it does not, it is blocked -- on a
+                // dead peer, on us -- and the abort below is what makes it return.  Either way the communicator is taken and aborted: none is left.
+                k.gate->cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return !k.gate->in_call; });
+                cm = k.comm; k.comm = nullptr;
+            }
+            if (cm) (void)rccl().CommAbort(cm);              // ends the kernels of stuck collectives and frees the communicator
         }
     { std::lock_guard<std::mutex> lk(M->mm); M->mcv.notify_all(); }
     { std::lock_guard<std::mutex> lk(M->bm); M->bcv.notify_all(); }
@@ -238,7 +271,7 @@ int kid_wait(vp_multi* M, Kid& k, const char* what)
         if (M->use_rccl && rccl().CommGetAsyncError && (spin & 63) == 63) {
             ncclResult_t ar = ncclSuccess;
             bool have = false;
-            { std::lock_guard<std::timed_mutex> lk(*k.comm_m); if (k.comm) have = rccl().CommGetAsyncError(k.comm, &ar) == ncclSuccess; }
+            if (ncclComm_t cm = comm_enter(M, k)) { CommLeave leave{k}; have = rccl().CommGetAsyncError(cm, &ar) == ncclSuccess; }
             if (have && ar != ncclSuccess && ar != ncclInProgress) {
                 multi_abort(M, k.rank, std::string(what) + ": asynchronous RCCL error: " + rccl().GetErrorString(ar));
                 return aborted_fail(M, c);
@@ -347,15 +380,16 @@ int p2p_batch(vp_multi* M, Kid& k, const std::vector<P2P>& ops, hipStream_t stre
     if (!stream) { stream = k.stream; const int rf = comm_fence(k); if (rf) return rf; }
     if (M->use_rccl) {
         Rccl& R = rccl();
-        std::lock_guard<std::timed_mutex> lk(*k.comm_m);
-        if (!k.comm) return aborted_fail(M, c);             // taken away by multi_abort
+        const ncclComm_t cm = comm_enter(M, k);
+        if (!cm) return aborted_fail(M, c);                 // aborted, or taken away by multi_abort
+        CommLeave leave{k};
         VP_NCCL(R.GroupStart());
         for (const P2P& o : ops) {
-            const ncclResult_t r = o.send ? R.Send(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, stream) : R.Recv(o.ptr, o.bytes, ncclUint8, o.peer, k.comm, stream);
+            const ncclResult_t r = o.send ? R.Send(o.ptr, o.bytes, ncclUint8, o.peer, cm, stream) : R.Recv(o.ptr, o.bytes, ncclUint8, o.peer, cm, stream);
             if (r != ncclSuccess) { (void)R.GroupEnd(); return vp_fail(c, VP_ERR_RCCL, "ncclSend/ncclRecv failed: %s", R.GetErrorString(r)); }
         }
         VP_NCCL(R.GroupEnd());
-        return VP_OK;
+        return M->aborted.load() ? aborted_fail(M, c) : VP_OK;   // aborted under the call: `cm` is gone, never touched again
     }
     // loopback: 1. post every receive buffer (never blocks), 2. do the sends (each waits for the peer's post), 3. wait for the receives
     std::vector<std::tuple<int, int, uint64_t>> mine;
@@ -425,10 +459,11 @@ int all_gather_inplace(vp_multi* M, Kid& k, float* buf, size_t count, hipStream_
     vp_ctx* c = k.c;
     if (!stream) { stream = k.stream; const int rf = comm_fence(k); if (rf) return rf; }
     if (M->use_rccl) {
-        std::lock_guard<std::timed_mutex> lk(*k.comm_m);
-        if (!k.comm) return aborted_fail(M, c);             // taken away by multi_abort
-        VP_NCCL(rccl().AllGather(buf + (size_t)k.rank * count, buf, count, ncclFloat, k.comm, stream));
-        return VP_OK;
+        const ncclComm_t cm = comm_enter(M, k);
+        if (!cm) return aborted_fail(M, c);                 // aborted, or taken away by multi_abort
+        CommLeave leave{k};
+        VP_NCCL(rccl().AllGather(buf + (size_t)k.rank * count, buf, count, ncclFloat, cm, stream));
+        return M->aborted.load() ? aborted_fail(M, c) : VP_OK;
     }
     std::vector<P2P> ops;
     for (int r = 0; r < M->world; ++r)
@@ -448,7 +483,7 @@ int copy_on_stream(Kid& k, void* dst, const void* src, size_t bytes)
     return VP_OK;
 }
 
-void free_kid(Kid& k)
+void free_kid(Kid& k, bool aborted = false)
 {
     if (!k.c && !k.stream) return;
     (void)hipSetDevice(k.device);
@@ -467,7 +502,11 @@ void free_kid(Kid& k)
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         (void)hipGetLastError();
     }
-    if (k.comm && rccl().so) (void)rccl().CommDestroy(k.comm);
+    if (k.comm && rccl().so) {
+        // a communicator of an ABORTED context that nobody took (no ncclCommAbort at abort time, or a kid created after it) may hold stuck
+        // operations: ncclCommDestroy would wait for them.  Abort it; destroy only communicators of a healthy context.
+        if (aborted && rccl().CommAbort) (void)rccl().CommAbort(k.comm); else if (!aborted) (void)rccl().CommDestroy(k.comm);
+    }
     void* bufs[] = {k.d_tau_all, k.d_img[0], k.d_img[1], k.d_tmaps, k.d_tout[0], k.d_tout[1], k.d_pieces, k.d_piece_out, k.d_final, k.d_xfer};
     for (void* p : bufs) if (p) (void)hipFree(p);
     for (auto& e : k.ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
@@ -599,7 +638,7 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
         std::string msg = what;
         for (Kid& k : M->kids) if (k.c && !k.c->err.empty()) msg += ": " + k.c->err;
         if (msg == what && !g_vp_create_error.empty()) msg += ": " + g_vp_create_error;
-        for (Kid& k : M->kids) free_kid(k);
+        for (Kid& k : M->kids) free_kid(k, M->aborted.load() != 0);
         delete M; delete P;
         return vp_fail(nullptr, code, "vp_create (fan-out): %s", msg.c_str());
     };
@@ -680,7 +719,7 @@ void multi_destroy(vp_ctx* P)
             M->cv_go.notify_all();
         }
         for (std::thread& t : M->threads) t.join();
-        for (Kid& k : M->kids) free_kid(k);
+        for (Kid& k : M->kids) free_kid(k, M->aborted.load() != 0);
         delete M;
     }
     delete P;
@@ -911,10 +950,10 @@ int multi_sync(vp_ctx* P)
     return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_sync"); return rw ? rw : vp_sync(k.c); }, false);
 }
 
-int multi_set_occluders(vp_ctx* P, const vp_obb* boxes, int32_t n)
+int multi_set_occluders(vp_ctx* P, const vp_occluder* boxes, int32_t n)
 {
     vp_multi* M = P->multi;
-    return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_set_occluders (previous frame's exchanges)"); return rw ? rw : vp_set_occluders(k.c, boxes, n); }, false);
+    return run_all(M, [&](Kid& k) -> int { const int rw = kid_wait(M, k, "vp_set_occluders (previous frame's exchanges)"); return rw ? rw : vp_set_occluders2(k.c, boxes, n); }, false);
 }
 
 vp_ctx* multi_owner_of_slice(vp_ctx* P, int zz)

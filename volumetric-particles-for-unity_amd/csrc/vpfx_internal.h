@@ -179,8 +179,8 @@ struct vp_ctx {
     const float* finish_tau_all = nullptr;   // vp_fill_finish_gathered: [world][LH][LW] transmittance maps, only during that call
     int finish_n_before = 0;
 
-    // occluder boxes (scene-occlusion inputs produced on the GPU)
-    vp_obb* d_occluders = nullptr;
+    // occluder solids (scene-occlusion inputs produced on the GPU)
+    vp_occluder* d_occluders = nullptr;
     int n_occluders = 0, occluders_cap = 0;
 
     // raymarch
@@ -289,7 +289,7 @@ int  multi_bin_resident(vp_ctx* c);
 int  multi_fill(vp_ctx* c, const vp_fill_params* p);
 int  multi_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp, float* host_out, void* d_out);
 int  multi_sync(vp_ctx* c);
-int  multi_set_occluders(vp_ctx* c, const vp_obb* boxes, int32_t n);
+int  multi_set_occluders(vp_ctx* c, const vp_occluder* solids, int32_t n);
 int  multi_get_stats(vp_ctx* c, vp_stats* st);
 int  multi_last_kernel_ms(vp_ctx* c, int stage, float* ms);
 int  multi_read_bincounts(vp_ctx* c, int32_t* counts);

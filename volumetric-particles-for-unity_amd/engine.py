@@ -234,9 +234,16 @@ class Engine:
     def composite_device(self, d_particles: int, d_scene: int):
         self._ck(self.L.vp_composite_device(self.h, C.c_void_p(d_particles), C.c_void_p(d_scene)), "vp_composite_device")
 
-    def set_occluders(self, boxes):
-        arr = (abi.vp_obb * len(boxes))(*boxes) if len(boxes) else None
-        self._ck(self.L.vp_set_occluders(self.h, arr, len(boxes)), "vp_set_occluders")
+    def set_occluders(self, solids):
+        """Boxes (abi.vp_obb) go through vp_set_occluders; any typed solid (abi.vp_occluder: cylinder, ellipsoid) sends the list through vp_set_occluders2."""
+        if all(isinstance(b, abi.vp_obb) for b in solids):
+            arr = (abi.vp_obb * len(solids))(*solids) if len(solids) else None
+            self._ck(self.L.vp_set_occluders(self.h, arr, len(solids)), "vp_set_occluders")
+        else:
+            self._ck(self.L.vp_set_occluders2(self.h, abi.as_occluders(solids), len(solids)), "vp_set_occluders2")
+
+    def set_occluders2(self, solids):
+        self._ck(self.L.vp_set_occluders2(self.h, abi.as_occluders(solids) if len(solids) else None, len(solids)), "vp_set_occluders2")
 
     def render_light_depth(self, near=0.3, far=1000.0, cam_distance=200.0):
         out = np.empty((self.N[1] * self.nv, self.N[0] * self.nv), dtype=np.float32)

@@ -4,8 +4,12 @@
 Same inspector field names (VPR.cs:72-101), same entry points and call order:
 
     Start()                      VPR.cs:132   create resources (vp_create)
-    OnPostRender(...)            VPR.cs:181   per-frame driver: gated bin+fill every `updateInterval` frames, ray-march
-                                              every frame, composite over the scene
+    OnPreRender(mainSceneRT)     VPR.cs:168   clear the scene target (particlesRT lives in the library: vp_raymarch starts from 0)
+    OnPostRender(...)            VPR.cs:181   per-frame driver: the opaque scene for the two depth inputs (SyncOccluders), gated bin+fill
+                                              every `updateInterval` frames, ray-march every frame, composite over the scene
+    SyncOccluders()              VPR.cs:184   vp_set_occluders2 when the solids changed (the library renders the light depth map inside
+                                              vp_fill and the eye depth inside vp_raymarch); or lightDepthMap / sceneDepth arrays passed as pointers
+    CompositeParticles(rt)       VPR.cs:210   CompositeParticles.shader:10
     UpdateMetavoxelPositions()   VPR.cs:370   vp_set_frame
     BinParticlesToMetavoxels()   VPR.cs:397   vp_bin
     FillMetavoxels()             VPR.cs:495   vp_fill               (one persistent launch)
@@ -55,8 +59,9 @@ class MetavoxelManager:
         self.wsGridCenter = np.zeros(3, dtype=np.float32)                       # VPR.cs:138
         self.psysLocalToWorld = np.eye(4, dtype=np.float32).T.reshape(16).copy()
         self.displacementCubemap = None                                         # float32 [6,S,S]
-        self.lightDepthMap = None                                               # optional
-        self.sceneDepth = None                                                  # optional
+        self.lightDepthMap = None                                               # optional: the C# shim's OccluderSource.UnityDepthTextures
+        self.sceneDepth = None                                                  # optional:   "
+        self._occluders, self._occluders_dirty = [], False                      # the C# shim's OccluderSource.SceneMeshes
         self._engine = None
         self._frame_dirty = True
         self._cubemap_dirty = True
@@ -98,25 +103,44 @@ class MetavoxelManager:
         except Exception:
             pass
 
+    def OnPreRender(self, mainSceneRT=None):
+        """VPR.cs:168-177.  particlesRT lives in the library and vp_raymarch starts from dst = 0 (the per-metavoxel path clears it with
+        vp_clear_particles_rt, see RenderMetavoxelsPerDraw); mainSceneRT is the host's: cleared to Color.black."""
+        if mainSceneRT is not None:
+            mainSceneRT[..., :3] = 0.0
+            mainSceneRT[..., 3] = 1.0
+
     def OnPostRender(self, frameCount, particles, layout, camera, mainSceneRT=None):
         """VPR.cs:181-220.  Returns particlesRT (and composites it over mainSceneRT in place when given)."""
         # the reference's first OnPostRender has frameCount % updateInterval == 0 (frame 0); a host that starts on another frame
         # would ray-march textures that were never filled, so the first call always bins + fills
         if len(self.gpuDevices) > 1 and self.rebalanceInterval > 0 and frameCount % self.rebalanceInterval == 0 and self._filled_once:
             self._engine.rebalance()                                            # re-cut the slabs from the work the GPUs measured
+        self.SyncOccluders()                                                    # :184 the light's (and the eye's) view of the opaque scene
         if frameCount % self.updateInterval == 0 or not self._filled_once:      # :186
             if self._frame_dirty:                                               # :188-195
                 self.UpdateMetavoxelPositions()
             self.BinParticlesToMetavoxels(particles, layout)                    # :197
             self.FillMetavoxels()                                               # :198
-        self.particlesRT = self.RenderMetavoxels(camera)                        # :207
+        self.particlesRT = self.RenderMetavoxels(camera)                        # :204-207
         if self.particlesRT is None:                                            # asyncReadback, first frame: nothing to show yet
             return None
-        if mainSceneRT is not None:                                             # Blit(particlesRT, mainSceneRT, matBlendParticles) :210
-            p = self.particlesRT
-            mainSceneRT[..., :3] = p[..., :3] + mainSceneRT[..., :3] * (1.0 - p[..., 3:4])
-            mainSceneRT[..., 3] = p[..., 3] + mainSceneRT[..., 3]
+        self.CompositeParticles(mainSceneRT)                                    # :210
         return self.particlesRT
+
+    def CompositeParticles(self, mainSceneRT):
+        """Blit(particlesRT, mainSceneRT, matBlendParticles) (VPR.cs:210; Comp.shader:10: Blend One OneMinusSrcAlpha, One One)."""
+        if mainSceneRT is None or self.particlesRT is None:
+            return
+        p = self.particlesRT
+        mainSceneRT[..., :3] = p[..., :3] + mainSceneRT[..., :3] * (1.0 - p[..., 3:4])
+        mainSceneRT[..., 3] = p[..., 3] + mainSceneRT[..., 3]
+
+    def SyncOccluders(self):
+        """Hand the opaque scene's solids to the library when they changed (the C# shim walks the Default-layer MeshRenderers here)."""
+        if self._occluders_dirty:
+            self._engine.set_occluders2(self._occluders)
+            self._occluders_dirty = False
 
     # ---- the hot path ------------------------------------------------------------------------------------
     def UpdateMetavoxelPositions(self):
@@ -251,10 +275,11 @@ class MetavoxelManager:
         self.wsGridCenter = np.ascontiguousarray(pos, dtype=np.float32)
         self._frame_dirty = True                                                # gridCenter moved: VPR.cs:189
 
-    def SetOccluders(self, boxes):
-        """Opaque scene geometry as boxes: the light depth map and the eye depth are then rendered on the GPU
-        (what lightCamera.RenderWithShader and the main camera's depth buffer provide in the reference, VPR.cs:184,204)."""
-        self._engine.set_occluders(list(boxes))
+    def SetOccluders(self, solids):
+        """Opaque scene geometry as solids (abi.vp_obb boxes / abi.vp_occluder boxes, cylinders, ellipsoids): the light depth map and the eye
+        depth are then rendered on the GPU (what lightCamera.RenderWithShader and the main camera's depth buffer provide in the reference,
+        VPR.cs:184,204).  Sent by the next SyncOccluders (= the next OnPostRender)."""
+        self._occluders, self._occluders_dirty = list(solids), True
 
     def SetDisplacementTexture(self, cubemap):
         self.displacementCubemap = cubemap

@@ -253,6 +253,23 @@ def make_box(center, half_extent, rot3=None) -> abi.vp_obb:
     return b
 
 
+def make_solid(kind, center, half_extent, rot3=None) -> abi.vp_occluder:
+    """Typed occluder (ABI 6): kind = abi.VP_OCC_BOX / VP_OCC_CYLINDER (axis = row 1 of `rot3`) / VP_OCC_ELLIPSOID."""
+    o = abi.vp_occluder()
+    C.memmove(C.byref(o), C.byref(make_box(center, half_extent, rot3)), C.sizeof(abi.vp_obb))
+    o.type = int(kind)
+    return o
+
+
+def unity_primitive(kind, position, quat=(0.0, 0.0, 0.0, 1.0), scale=(1.0, 1.0, 1.0), parent_position=(0.0, 0.0, 0.0)) -> abi.vp_occluder:
+    """A Unity built-in primitive mesh under a Transform (position, rotation quaternion, scale; parent = a pure translation):
+    Cube (mesh 10202) spans [-0.5, 0.5]^3, Cylinder (mesh 10206) has radius 0.5 and height 2 about its local y, Sphere (mesh 10207) radius 0.5."""
+    sx, sy, sz = (float(v) for v in scale)
+    half = (0.5 * sx, sy, 0.5 * sz) if kind == abi.VP_OCC_CYLINDER else (0.5 * sx, 0.5 * sy, 0.5 * sz)
+    center = np.asarray(position, dtype=np.float64) + np.asarray(parent_position, dtype=np.float64)
+    return make_solid(kind, center, half, quat_to_matrix(quat).T)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The demo scene of the reference (Assets/Volumetric_Particle_System.unity) -- SURVEY section 8(f) row 3
 # ---------------------------------------------------------------------------------------------------------------
@@ -307,7 +324,8 @@ class DemoEmitter:
 def make_demo_scene(width=1024, height=768, warm_seconds=6.0, seed=7):
     """The reference's scene: 10^3 metavoxels x 32^3 voxels of size 3 (scene:9013-9016), main camera at (-10,0,-20) looking
     +z with fov 60, directional light quaternion (0.1856,0,0,0.9826), grid centre at world (0,-5,0), particle system at world
-    (0,0,11.2) rotated 180 deg about Y, ground / back planes and two cubes as occluder boxes.  Returns (scene, emitter, boxes)."""
+    (0,0,11.2) rotated 180 deg about Y, and the scene's eight opaque meshes as occluder solids: ground / back (scaled cubes), two cubes, four
+    cylinders.  Returns (scene, emitter, solids)."""
     em = DemoEmitter(seed=seed)
     steps = int(round(warm_seconds * 30))
     for _ in range(steps):
@@ -324,10 +342,19 @@ def make_demo_scene(width=1024, height=768, warm_seconds=6.0, seed=7):
     c2w[:3, 3] = (-10.0, 0.0, -20.0)
     sc.cam_to_world, sc.world_to_cam = c2w, np.linalg.inv(c2w)
     sc.cam_pos = np.array([-10.0, 0.0, -20.0], dtype=np.float32)
+    # every MeshRenderer of the scene on the Default layer (VPR.cs:346 lightCamera.cullingMask; the main camera draws them too), all children of
+    # the object "Scene" at (0,-5,0) (scene:6525-6533): ground and back are CUBES (mesh 10202) scaled (50,1,50) -- scene:4703-4760, 6313-6382 --,
+    # "Cube" / "Cube 1" unit cubes, "Cylinder" / "Cylinder 1" / "Cylinder 2" / "Cylinder 3" unit cylinders (mesh 10206: radius 0.5, height 2;
+    # scene:8623, 1755, 8382, 5462; "Cylinder 1" and "Cylinder 2" coincide in the scene file)
+    par = (0.0, -5.0, 0.0)
     boxes = [
-        make_box((0.0, -6.52 - 0.05, 0.0), (250.0, 0.05, 250.0)),                    # ground plane (10x10 mesh, scale 50)
-        make_box((0.0, 19.0, 24.5 + 0.05), (250.0, 250.0, 0.05)),                    # back wall (plane rotated 90 deg about x)
-        make_box((-5.34, 1.18, -11.89), (0.5, 0.5, 0.5)),                            # Cube
-        make_box((0.0, -0.43, -11.0), (0.5, 0.5, 0.5)),                              # Cube 1
+        unity_primitive(abi.VP_OCC_BOX, (0.0, -1.52, 0.0), scale=(50.0, 1.0, 50.0), parent_position=par),                               # ground
+        unity_primitive(abi.VP_OCC_BOX, (0.0, 24.0, 24.5), quat=(0.707106829, 0.0, 0.0, 0.707106829), scale=(50.0, 1.0, 50.0), parent_position=par),  # back
+        unity_primitive(abi.VP_OCC_BOX, (-5.34, 6.18, -11.89), parent_position=par),                                                    # Cube
+        unity_primitive(abi.VP_OCC_BOX, (0.0, 4.57, -11.0), parent_position=par),                                                       # Cube 1
+        unity_primitive(abi.VP_OCC_CYLINDER, (-8.24, 0.0, 0.0), parent_position=par),                                                   # Cylinder
+        unity_primitive(abi.VP_OCC_CYLINDER, (0.0, 0.0, 0.0), parent_position=par),                                                     # Cylinder 1
+        unity_primitive(abi.VP_OCC_CYLINDER, (0.0, 0.0, 0.0), parent_position=par),                                                     # Cylinder 2
+        unity_primitive(abi.VP_OCC_CYLINDER, (1.45, -1.05, 9.11), parent_position=par),                                                 # Cylinder 3
     ]
     return sc, em, boxes
