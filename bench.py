@@ -167,6 +167,12 @@ def main():
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the untimed content variants after the timed region (float cube map, coloured ambient, +x view: `variants` in the JSON line)")
     args = ap.parse_args()
+    # TEST HOOKS (tests/test_gpu_bench_cli.py runs the DRIVER'S command line byte for byte on a one-GPU box, so the switches cannot be flags):
+    #   VPFX_BENCH_SHARE_GPU=1        = --share-gpu
+    #   VPFX_BENCH_TEST_FAIL_RANK=r   rank r dies (os._exit) in the middle of the timed region: the job must exit non-zero, not hang
+    if os.environ.get("VPFX_BENCH_SHARE_GPU") == "1":
+        args.share_gpu = True
+    fail_rank = int(os.environ.get("VPFX_BENCH_TEST_FAIL_RANK", "-1"))
     # stdout carries the JSON line and nothing else: everything any library prints there (gloo announces its connections on stdout from C++,
     # one line per rank, interleaved) is sent to stderr for the rest of the run; rank 0 writes the line to the saved descriptor at the end
     sys.stdout.flush()
@@ -315,6 +321,9 @@ def main():
     # waits per frame are a third of a 0.3 ms frame.  So they are read on every stride-th step (>= 64 samples of every stage per run).
     stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // 64)
     for i in range(args.steps):
+        if rank == fail_rank and i == args.steps // 2:
+            print(f"[bench] TEST HOOK: rank {rank} leaves the job at timed step {i}", file=sys.stderr, flush=True)
+            os._exit(17)
         step()
         if i % stride == stride - 1 or i == args.steps - 1:
             k_bin.append(eng.last_kernel_ms(0)); k_fill.append(eng.last_kernel_ms(1)); k_rm.append(eng.last_kernel_ms(2))

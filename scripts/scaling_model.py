@@ -18,7 +18,10 @@ For every (N, hand-off groups):
      (slab 0, nearest the light, runs the fused fill: fill_local_0 = its fused kernel, finish_0 = 0)
 The exchange terms are xGMI ESTIMATES (one link ~50 GB/s usable per direction, seven links per GPU, ~40 us software latency per RCCL call),
 stated in the output; everything else is measured.  The host side is the library's worker threads (one per GPU), not modelled: each
-issues ~25 launches per frame.  usage: scaling_model.py [C3] [r8|f32]"""
+issues ~25 launches per frame.  usage: scaling_model.py [C3|C5] [r8|f32]
+C5 (round 6; BASELINE.json's only 8-GPU config: 64^3 x 64^3, 1 M particles, 3840 x 2160): the fan-out context of step 1 holds all N slabs on
+this one GPU (the whole ~190 GB brick pool + the per-rank exchange buffers); worlds 2 / 4 / 8, one or two hand-off groups; the per-rank
+brick bytes are recorded (what each of the N GPUs has to hold); the alternative 8-GPU plan is skipped."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -59,8 +62,9 @@ def frame(e, first=False):
     e.bin_resident(); e.fill(sc.fill_params()); e.raymarch_device(cam, rp, img.data_ptr())
 
 
-for world in (2, 4, 7, 8):                # (7: the slab cut of the alternative 8-GPU plan below)
-    for groups in (sorted({1, 2, world}) if world != 7 else [1]):
+BIG = sc.N[2] > 32
+for world in ((2, 4, 8) if BIG else (2, 4, 7, 8)):                # (7: the slab cut of the alternative 8-GPU plan below)
+    for groups in ([1, 2] if BIG else sorted({1, 2, world}) if world != 7 else [1]):
         # 1. the library's own cut, chain and groups
         m = E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY, rm_groups=groups))
         m.set_frame(sc.light_to_world, sc.grid_center)
@@ -97,7 +101,7 @@ for world in (2, 4, 7, 8):                # (7: the slab cut of the alternative 
             st = e.stats()
             maps[r] = (t_out[0].clone(), t_out[1].clone())
             rows[r] = dict(slab=[cuts[r], cuts[r + 1]], group=group_of[r], bin=e.last_kernel_ms(0), fill_local=e.last_kernel_ms(1), finish=e.last_kernel_ms(3) if r else 0.0,
-                           rm=e.last_kernel_ms(2), samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"])
+                           rm=e.last_kernel_ms(2), samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"], brick_bytes=st["brick_bytes"])
             e.close(); del tau_all, over, under
             torch.cuda.empty_cache()
         # 3. the pipeline
@@ -135,6 +139,10 @@ for world in (2, 4, 7, 8):                # (7: the slab cut of the alternative 
 # six ranks share the remaining slices.  Seven distinct slabs = the library's cut for world 7 (measured above); the two halves of the front
 # slab's ray-march are measured for real: a scene-depth buffer of 0 on the other half of the screen rejects every metavoxel there (ZTest Less,
 # RM.shader:14), the split column halves the executed samples (from the samples-per-ray view).
+os.makedirs("gpurun_out/r6_scaling", exist_ok=True)
+json.dump(out, open(f"gpurun_out/r6_scaling/scaling_model_{name}_{cube}.json", "w"), indent=1)
+if BIG:
+    sys.exit(0)
 p7 = out["predictions"]["7gpu_1groups"]
 cuts7 = p7["slab_cuts"]
 e = E.Engine(sc.config(device=0, slab=(cuts7[0], cuts7[1])))
@@ -170,5 +178,4 @@ print(f"ALTERNATIVE at 8 GPUs -- front slab {cuts7[:2]} filled on two ranks, scr
       f"{halves[0]['rm']:.3f} / {halves[1]['rm']:.3f} ms (whole: {rows7[0]['rm']:.3f}), max bin+fill_local {fill_max:.2f} (8 slabs: "
       f"{max(x['bin'] + x['fill_local'] for x in out['predictions']['8gpu_1groups']['per_rank']):.2f}), max after the all-gather {after7:.2f}: "
       f"predicted {t_alt * 1e3:.2f} ms/step vs {base8:.2f} for eight slabs -> {'BEATS' if t_alt * 1e3 < base8 else 'does NOT beat'} it", flush=True)
-os.makedirs("gpurun_out/r5_scaling", exist_ok=True)
-json.dump(out, open(f"gpurun_out/r5_scaling/scaling_model_{name}_{cube}.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/r6_scaling/scaling_model_{name}_{cube}.json", "w"), indent=1)

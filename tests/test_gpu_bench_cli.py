@@ -126,3 +126,64 @@ def test_one_process_per_gpu_launch_runs_to_its_json_line_on_the_multiprocess_st
     ms = pr["kernel_ms_bin_fill_raymarch_finish"]
     assert all(row[1] > 0 for row in ms) and ms[0][3] == 0 and all(row[3] > 0 for row in ms[1:])     # every process reported; finish pass on ranks > 0 only
     assert d["scaling"] == "strong" and d["value"] > 0 and exchange in c["parallelism"]
+
+
+# ---- first-hardware-run hardening: the DRIVER'S command lines, byte for byte ------------------------------------------
+def _driver_command(n, port, steps=20, warmup=5):
+    """What the driver runs for N > 1 (task contract): `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- default config (C3), default flags."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+            "bench.py", "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup)]
+
+
+def _driver_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # one GPU under N ranks: every rank on cuda:0 (env form of --share-gpu) and the multi-process stand-in as the RCCL build libvpfx dlopens
+    env.update(VPFX_BENCH_SHARE_GPU="1", VPFX_RCCL_LIBRARY=MP_SHIM, FAKE_RCCL_TIMEOUT_MS="60000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra)
+    return env
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_the_drivers_scaling_command_runs_to_one_json_line(n):
+    """`--steps 20 --warmup 5`, everything else default: the metric's config (C3: 32^3 x 32^3, 100 k particles, 1920 x 1080) in N slabs, one process
+    per rank.  ONE JSON line on stdout; N RCCL ranks; per-rank figures from every process; the sharded frame = the 1-GPU frame rendered on rank 0."""
+    _build_mp_shim()
+    r = subprocess.run(_driver_command(n, _free_port()), cwd=ROOT, env=_driver_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-3000:]
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    c = d["config"]
+    assert d["n_gpus"] == n and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong" and d["value"] > 0
+    assert c["workload"].startswith("C3") and c["rccl_ranks"] == n and "one process per GPU" in c["launch"]
+    assert len(c["slabs"]) == n and c["slabs"][0][0] == 0 and c["slabs"][-1][1] == 32
+    assert c["max_abs_rgba_diff_vs_1gpu_frame"] is not None and c["max_abs_rgba_diff_vs_1gpu_frame"] <= 2e-5
+    pr = d["per_rank"]
+    assert len(pr["samples"]) == n and len(pr["kernel_ms_bin_fill_raymarch_finish"]) == n and all(row[1] > 0 for row in pr["kernel_ms_bin_fill_raymarch_finish"])
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d                       # the CPU leg is rank 0's at N = 1 only
+    assert d["metric"].startswith("Mvoxels/s filled")
+
+
+def test_a_rank_that_dies_mid_run_ends_the_job_nonzero_instead_of_hanging():
+    """Rank 1 of 4 leaves in the middle of the timed region (os._exit: no clean-up, as a crashed process).  Its peers sit in exchanges with it:
+    the library's bounded waits (and torchrun's worker watchdog) must end the whole command with a non-zero exit code well inside the time-out,
+    and no JSON line may be printed."""
+    import time
+    _build_mp_shim()
+    t0 = time.time()
+    r = subprocess.run(_driver_command(4, _free_port(), steps=10, warmup=3), cwd=ROOT,
+                       env=_driver_env(VPFX_BENCH_TEST_FAIL_RANK="1", FAKE_RCCL_TIMEOUT_MS="20000"), capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert r.returncode != 0, (r.stdout + r.stderr)[-3000:]
+    assert took < 300, took
+    assert not any(l.startswith("{") for l in r.stdout.splitlines()), r.stdout[-2000:]
+    assert "TEST HOOK: rank 1 leaves the job" in r.stderr

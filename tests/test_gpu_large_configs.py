@@ -99,3 +99,123 @@ def test_config5_full_size_on_one_gpu():
     o.close()
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def _fp16_ulp_diff_max(a, b):
+    """Largest distance in fp16 code points between two uint16 arrays of NON-NEGATIVE halves (positive halves are ordered like their codes)."""
+    return int(np.abs(a.view(np.int16).astype(np.int32) - b.view(np.int16).astype(np.int32)).max())
+
+
+def test_config5_through_the_fanout_slab_by_slab():
+    """BASELINE.json configs[4] -- the only config assigned to 8 GPUs -- SHARDED, on one GPU: the eight light-axis slab
+    contexts the library's planner cuts are created ONE AT A TIME (each ~1/8 of the 190 GB brick pool) next to the resident single-context C5,
+    and driven through the fan-out's building blocks in rank order: vp_fill_local -> tau (carried on the HOST between contexts, as the
+    all-gather would carry it between GPUs) -> vp_fill_finish_gathered -> vp_raymarch_partial_device.  Checked against the single context:
+      (i)  EVERY brick of two layers per slab (its first and its last): densities bit-identical everywhere; lit colours bit-identical in the
+           slab nearest the light and within 1 fp16 ulp behind it (T_in is a product of slab transmittances: fp32 reassociation; Fill.shader:224,250
+           carries the same light through the UAV slice by slice); the final light map (the last slab's);
+      (ii) the ORDERED blend of the partial images (VPR.cs:652-711 at slab granularity) against the single-context 4K frame (<= 2e-5), for the
+           benchmark camera (all UNDER) and for a camera whose zBoundary falls inside the grid (OVER and UNDER phases, one straddling slab);
+      and the shards PARTITION the work: occupied metavoxels, pairs and executed lattice samples add up to the single context's."""
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 240e9:
+        assert total < 250e9, f"needs ~190 GB (whole grid) + ~30 GB (one slab) of free HBM; only {free / 1e9:.0f} of {total / 1e9:.0f} GB are free"
+        pytest.skip(f"device has {total / 1e9:.0f} GB in total")
+    dev = torch.device("cuda", 0)
+    world = 8
+    sc = S.make_scene("C5", cubemap="r8")                          # the benchmark's texel format: k_fill_lds<64>
+    cams = [("benchmark", None), ("straddling", (24.0, 240.0, 16.0))]
+    single = E.Engine(sc.config(), exact=True, early_out=False)
+    single.set_frame(sc.light_to_world, sc.grid_center)
+    single.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+    hist = [float(x) for x in single.z_histogram()]
+    single.bin_resident()
+    single.fill(sc.fill_params())
+    cnt = single.bin_counts()
+    st1 = single.stats()
+    assert st1["occupied_mv"] == 80226
+    lm_single = single.read_lightmap()
+    rp = sc.raymarch_params()
+    frames, samples1, zbs, cam_structs = {}, {}, {}, {}
+    for name, pos in cams:
+        if pos is not None:
+            sc.set_camera(pos)
+        cam_structs[name] = sc.camera()
+        img = torch.empty((sc.height, sc.width, 4), device=dev)
+        single.raymarch_device(cam_structs[name], rp, img.data_ptr())
+        single.sync()
+        frames[name], samples1[name], zbs[name] = img, single.stats()["samples"], single.z_boundary(cam_structs[name])
+    assert zbs["benchmark"] == -1 and 0 <= zbs["straddling"] < sc.N[2] - 1, zbs
+    # the cut a fan-out context makes at its first vp_bin: the library's planner on the pair histogram
+    bounds = E.plan_slabs(sc.N[2], world, fill_ms=hist, rm_ms=None)
+    assert bounds[0][0] == 0 and bounds[-1][1] == sc.N[2] and all(z1 > z0 for z0, z1 in bounds) and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+    lm_shape = (sc.N[1] * sc.nv, sc.N[0] * sc.nv)
+    taus_host = []                                                   # what travels between the ranks: 64 MiB per slab
+    parts = {name: {} for name, _ in cams}
+    occupied = pairs = 0
+    samples = {name: 0 for name, _ in cams}
+    bricks_checked = worst_ulp = 0
+    lm_last = None
+    for r, (z0, z1) in enumerate(bounds):
+        e = E.Engine(sc.config(device=0, slab=(z0, z1)), exact=True, early_out=False)
+        e.set_frame(sc.light_to_world, sc.grid_center)
+        e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+        e.bin_resident()
+        tau = torch.empty(lm_shape, device=dev)
+        e.fill_local(sc.fill_params(), tau.data_ptr())
+        e.sync()
+        taus_host.append(tau.cpu())
+        tau_all = torch.ones((world,) + lm_shape, device=dev)      # slabs behind this one: never read by rank r's finish pass
+        for j, t in enumerate(taus_host):
+            tau_all[j].copy_(t)
+        e.fill_finish_gathered(tau_all.data_ptr(), r, world)
+        st = e.stats()
+        occupied += st["occupied_mv"]; pairs += st["pairs"]
+        assert st["brick_bytes"] < 0.25 * st1["brick_bytes"], "a slab context must hold its slab's bricks only"
+        # (i) every brick of the slab's first and last layer
+        for zz in sorted({z0, z1 - 1}):
+            ys, xs = np.nonzero(cnt[zz])
+            for yy, xx in zip(ys, xs):
+                a, b = single.read_brick(xx, yy, zz).view(np.uint16), e.read_brick(xx, yy, zz).view(np.uint16)
+                bricks_checked += 1
+                if np.array_equal(a, b):
+                    continue
+                assert r > 0, f"slab 0 brick {(xx, yy, zz)} differs from the single context's"
+                assert np.array_equal(a[..., 3], b[..., 3]), f"density of brick {(xx, yy, zz)} differs"
+                u = _fp16_ulp_diff_max(a[..., :3], b[..., :3])
+                worst_ulp = max(worst_ulp, u)
+                assert u <= 1, f"brick {(xx, yy, zz)}: {u} fp16 ulps"
+        # (ii) the slab's partial images for both cameras
+        for name, _ in cams:
+            over, under = torch.empty((sc.height, sc.width, 4), device=dev), torch.empty((sc.height, sc.width, 4), device=dev)
+            e.raymarch_partial_device(cam_structs[name], rp, over.data_ptr(), under.data_ptr())
+            e.sync()
+            samples[name] += e.stats()["samples"]
+            parts[name][r] = (over, under)
+        if r == world - 1:
+            lm_last = e.read_lightmap()
+        e.close()
+        del tau_all, tau
+        torch.cuda.empty_cache()
+    assert occupied == st1["occupied_mv"] and pairs == st1["pairs"]
+    assert bricks_checked > 8000, bricks_checked
+    np.testing.assert_allclose(lm_last, lm_single, rtol=2e-5, atol=1e-9)
+    blender = E.Engine(S.make_scene("C5").config(device=0, slab=(0, 1)))      # any context of this screen size blends (no bricks needed)
+    for name, _ in cams:
+        assert samples[name] == samples1[name], (name, samples[name], samples1[name])      # every lattice sample is executed by exactly one slab
+        chain, plan, straddler = E.blend_plan(bounds, zbs[name])
+        assert (straddler is None) == (name == "benchmark")
+        imgs = [parts[name][rk][kind] for rk, _, kind in plan]                 # kind 0: the slab's OVER image, 1: its UNDER image
+        out = torch.empty((sc.height, sc.width, 4), device=dev)
+        blender.blend_partials_device([t.data_ptr() for t in imgs], [k for _, _, k in plan], out.data_ptr())
+        blender.sync()
+        err = float((out - frames[name]).abs().max().item())
+        assert err <= 2e-5, (name, err)
+        assert float(frames[name][..., 3].mean().item()) > 0.3
+    print(f"[C5 slab by slab] cut {bounds}; bricks compared {bricks_checked}, worst {worst_ulp} fp16 ulp; samples {samples}")
+    blender.close()
+    single.close()
+    gc.collect()
+    torch.cuda.empty_cache()

@@ -275,6 +275,9 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
 #ifndef VPFX_BYTE_DENORM
 #define VPFX_BYTE_DENORM 1
 #endif
+#ifndef VPFX_SMOOTH_SKIP
+#define VPFX_SMOOTH_SKIP 0
+#endif
 template <bool EXACT, bool DONE, bool BYTES = false>
 __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
                                            const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
@@ -291,6 +294,18 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
     }
     const float raw = fmaf(ty, b - a, a);
     net = fmaf(Dk, raw, one_minus_D);                                             // netDisplacement   :119
+#if VPFX_SMOOTH_SKIP
+    // A/B (VERDICT r5 next #6a; PERFLOG round 6): wave-uniform smoothstep skip.  smoothstep(net, 0.7 net, 4 d2) is exactly 1 where
+    // 4 d2 <= 0.7 net (the sphere's core) and exactly 0 where 4 d2 >= net; when EVERY covered lane of the wave-slice is in the core (or every
+    // one outside the displaced surface) the reciprocal, the clamped FMA and the cubic are skipped.  Margins (0.69 / 1.01) keep the skipped
+    // lanes where the fast path's t, computed with v_rcp_f32, clamps to exactly 1 / 0: bit-identical to the build without the skip.
+    // (called inside `if (hit)`: the ballot sees the covered lanes only)
+    if (!EXACT && !DONE) {
+        const float d2q = 4.0f * d2;
+        if (__builtin_amdgcn_ballot_w64(d2q > 0.69f * net) == 0) { const float k = f.opacity_factor * opw; den = fmaf(1.0f, -2.0f * k, 3.0f * k); return; }
+        if (__builtin_amdgcn_ballot_w64(d2q < 1.01f * net) == 0) { den = 0.f; return; }
+    }
+#endif
     float t;
     if (EXACT) {
         const float d2q = 4.0f * d2;                                              // dot(2ps, 2ps)     :121
