@@ -397,6 +397,36 @@ def main():
         run_variant("view_plus_x", fp_first, fp, camera=sc_x.camera(), note="camera on the grid's +x axis (brick rows run along x)")
         eng.bin_resident(); eng.fill(fp_first)                      # leave the context as the timed region did
         barrier()
+        # the same grid, particles and view with a voxel count that is none of 16 / 32 / 64 (VPR.cs:84 is a free inspector int): the run-time-nv
+        # instantiations (fill_generic.hip / raymarch_generic.hip) on a second context, 20 steps
+        if sc.nv in (16, 32, 64) and f"{args.config}nv24" in S.CONFIGS:
+            sc_g = S.make_scene(f"{args.config}nv24", cubemap=args.cubemap)
+            eg = E.Engine(sc_g.config(device=local_rank))
+            eg.set_frame(sc_g.light_to_world, sc_g.grid_center)
+            eg.upload_particles(sc_g.particles, sc_g.layout, sc_g.psys_local_to_world)
+            g_first, g_next = sc_g.fill_params(), sc_g.fill_params()
+            g_next.cubemap = None
+            cam_g, rp_g = sc_g.camera(), sc_g.raymarch_params()
+            eg.bin_resident(); eg.fill(g_first); eg.raymarch_device(cam_g, rp_g, image.data_ptr())
+            for _ in range(2):
+                eg.bin_resident(); eg.fill(g_next); eg.raymarch_device(cam_g, rp_g, image.data_ptr())
+            eg.sync(); torch.cuda.synchronize()
+            tv = time.perf_counter()
+            kf, kr = [], []
+            for i in range(20):
+                eg.bin_resident(); eg.fill(g_next); eg.raymarch_device(cam_g, rp_g, image.data_ptr())
+                if i % 5 == 4:
+                    kf.append(eg.last_kernel_ms(1)); kr.append(eg.last_kernel_ms(2))
+            eg.sync(); torch.cuda.synchronize()
+            ms = (time.perf_counter() - tv) / 20 * 1e3
+            sg = eg.stats()
+            variants["generic_nv24"] = {
+                "fill_ms": float(np.mean(kf)), "raymarch_ms": float(np.mean(kr)), "ms_per_step": ms, "samples_per_step": int(sg["samples"]),
+                "voxels_per_step": int(sg["voxels_filled"]), "brick_format": "grey z-pair" if sg.get("brick_format", 0) == 1 else "RGBA16F",
+                "value": (sg["voxels_filled"] + sg["samples"]) / (ms * 1e-3) / 1e6,
+                "fill_ns_per_kvoxel": float(np.mean(kf)) * 1e6 / (sg["voxels_filled"] / 1e3), "headline_fill_ns_per_kvoxel": float(np.mean(k_fill)) * 1e6 / (voxels / 1e3),
+                "what": f"{sc_g.N[0]}^3 metavoxels x 24^3 voxels (same particles and view): the run-time voxel-count kernels (GEN k_fill_lds / k_raymarch<0>)"}
+            eg.close()
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

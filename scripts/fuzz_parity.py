@@ -1,6 +1,6 @@
 """Randomised HIP-vs-oracle parity sweep (GPU box): random grids (cubic and not), voxel counts, borders, metavoxel scales, particle
 sets, light rotations, particle-system transforms, cameras all around (inside too), fade / radians / soft-distance / step options,
-random light depth maps and scene depth.  Every case checks: identical bin counts, bricks (bit-identical in exact mode, <= 1 fp16
+random light depth maps and scene depth, opaque solids (third generation of seeds).  Every case checks: identical bin counts, bricks (bit-identical in exact mode, <= 1 fp16
 ulp in fast mode), light map, RGBA <= 1e-3 and -- with the early-out off -- the oracle's sample count.
 usage: fuzz_parity.py [cases] [first_seed]"""
 import math
@@ -18,6 +18,7 @@ from oracle import oracle as O
 
 
 ANY_NV_FIRST_SEED = 1_000_000
+OCCLUDER_FIRST_SEED = 3_000_000          # third generation (round 6): opaque solids (boxes, capped cylinders, ellipsoids; ABI 6) in 60 % of the scenes
 
 
 def rand_quat(rng):
@@ -76,6 +77,25 @@ def make_case_scene(seed):
         sc.displacement_scale = float(r8.choice([0.7, 0.7, r8.uniform(0.0, 1.0), 1.0]))
     if r8.random() < 0.3:       # a coloured ambient keeps RGBA16F bricks (grey ambient: luminance | density storage)
         sc.ambient = tuple(float(x) for x in r8.uniform(0.0, 0.5, 3))
+    sc.occluders = None
+    if seed >= OCCLUDER_FIRST_SEED:
+        ro = np.random.default_rng(seed + 1977)
+        if ro.random() < 0.6:
+            from vpfx_amd import abi
+            ext = 0.5 * max(sc.N) * sc.mv_scale
+            gc_ = np.asarray(sc.grid_center, dtype=np.float64)
+            sol = []
+            for _ in range(int(ro.integers(1, 5))):
+                kind = int(ro.choice([abi.VP_OCC_BOX, abi.VP_OCC_CYLINDER, abi.VP_OCC_CYLINDER, abi.VP_OCC_ELLIPSOID]))
+                half = ro.uniform(0.05, 0.45, 3) * ext
+                rot = S.quat_to_matrix(rand_quat(ro)).T if ro.random() < 0.7 else np.eye(3)
+                if ro.random() < 0.25:   # axis along the light direction: the light rays run parallel to a cylinder's axis (the quadric's degenerate branch)
+                    Lm = np.asarray(sc.light_to_world, dtype=np.float64).reshape(4, 4).T[:3, :3]
+                    rot = np.stack([Lm[:, 0], Lm[:, 2], -Lm[:, 1]])
+                sol.append(S.make_solid(kind, gc_ + ro.uniform(-0.7, 0.7, 3) * ext, half, rot))
+            if ro.random() < 0.3:        # a ground slab under everything
+                sol.append(S.make_box(gc_ + np.array([0.0, -ro.uniform(0.2, 0.9) * ext, 0.0]), (4 * ext, 0.05 * ext, 4 * ext)))
+            sc.occluders = sol
     return sc, rng
 
 
@@ -89,8 +109,14 @@ def one_case(seed):
     ge = E.Engine(sc.config(), exact=exact)
     for x in (o, g, ge):
         x.set_frame(sc.light_to_world, sc.grid_center)
+        if sc.occluders:
+            x.set_occluders(sc.occluders)              # both depth inputs are then rendered from the solids (same fp32 operation order on both sides)
         x.bin(sc.particles, sc.layout, sc.psys_local_to_world)
         x.fill(sc.fill_params())
+    if sc.occluders:
+        np.testing.assert_array_equal(g.render_light_depth(), o.render_light_depth(), "light depth map rendered from the solids")
+        so_, sg_ = o.render_scene_depth(sc.camera()), g.render_scene_depth(sc.camera())
+        assert np.array_equal(so_ < 1e30, sg_ < 1e30) and np.allclose(sg_, so_, rtol=1e-6), "eye depth rendered from the solids"
     co = o.bin_counts()
     assert np.array_equal(co, g.bin_counts()), "bin counts"
     worst, worst_abs = 0, 0.0
@@ -125,6 +151,8 @@ def one_case(seed):
         for r in range(world):
             e = E.Engine(sc.config(device=0, slab=bounds[r]), exact=exact, early_out=bool(rng.integers(0, 2)))
             e.set_frame(sc.light_to_world, sc.grid_center)
+            if sc.occluders:
+                e.set_occluders(sc.occluders)
             e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
             engs.append(PAR.HipSlabEngine(e, torch.device("cuda", 0)))
         taus = []
@@ -152,6 +180,8 @@ def one_case(seed):
         mflags = abi.VP_MULTI_PEER_COPY | (abi.VP_MULTI_EXCHANGE_ALL_GATHER if rng.integers(0, 2) else 0) | (abi.VP_MULTI_UNIFORM_SLABS if rng.integers(0, 3) == 0 else 0)
         mf = E.Engine(sc.config(devices=[0] * wf, multi_flags=mflags, rm_groups=int(rng.integers(0, wf + 1))), exact=exact)
         mf.set_frame(sc.light_to_world, sc.grid_center)
+        if sc.occluders:
+            mf.set_occluders(sc.occluders)
         mf.bin(sc.particles, sc.layout, sc.psys_local_to_world)
         mf.fill(sc.fill_params())
         imf = mf.raymarch(cam, rp)

@@ -3,7 +3,7 @@
 8^depth, depth = number of loops (backward branches) enclosing it.  Together with the per-opcode issue rates and class membership measured by
 scripts/probes/valu_rate_probe.hip under rocprofv3 (profiles/r04_valu_classes.json) this gives, per SQ_INSTS_VALU_* class counter, the average
 issue cycles of an instruction of that class IN THIS KERNEL -- what scripts/limiters_json.py multiplies the class counters of a profiled run with.
-usage: isa_mix.py profiles/r04_valu_classes.json out.json   (compiles csrc/fill.hip and csrc/raymarch.hip: ~2 minutes)"""
+usage: isa_mix.py profiles/r04_valu_classes.json out.json   (compiles csrc/fill.hip, raymarch.hip and the two *_generic.hip units: ~3 minutes)"""
 import json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "volumetric-particles-for-unity_amd", "csrc")
@@ -75,12 +75,14 @@ def kernel_sources_sha():
             h.update(fn.encode() + b"\0" + open(os.path.join(CSRC, fn), "rb").read())
     return h.hexdigest()[:16]
 out = {"method": __doc__.split("usage")[0].strip(), "kernel_sources_sha": kernel_sources_sha(), "kernels": {}}
-for src in ("fill", "raymarch"):
+for src in ("fill", "raymarch", "fill_generic", "raymarch_generic"):
     fns = dict(functions(listing(src)))
     dm = demangle(list(fns))
     for mangled, body in fns.items():
         name = dm[mangled].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        if re.match(r"k_fill_lds<(32|64), 0, 1, false(, false)?>|k_raymarch<(32|64), false, false, false, true>|k_fill<(32|64), 0, 0, true(, false)?>", name):
+        # the headline instantiations + (round 6) the cliff / any-nv paths profiled by scripts/gpu_prof_r6.sh: RGBA16F bricks (GREY = false), run-time voxel count
+        if re.match(r"k_fill_lds<(32|64), 0, 1, false(, false)?>|k_raymarch<(32|64), false, false, false, (true|false)>|k_fill<(32|64), 0, 0, true(, false)?>|"
+                    r"k_fill_lds<(32|64), 0, 2, false, true>|k_fill<(32|64), 0, 0, true, true>|k_raymarch<0, false, false, false, (true|false)>", name):
             out["kernels"][name] = mix(body)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k, v in out["kernels"].items(): print(k, {c: round(d["avg_issue_cycles"], 2) for c, d in v.items()})

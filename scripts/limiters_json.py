@@ -35,9 +35,10 @@ for db in ([] if RECORDED_SHA else sys.argv[2:]):
         con.close()
 SIMDS = 1024
 try:
-    _m = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_mix.json")))
+    _p = os.path.join(ROOT, "profiles", "r06_isa_mix.json")
+    _m = json.load(open(_p if os.path.exists(_p) else os.path.join(ROOT, "profiles", "r05_isa_mix.json")))
     ISA_MIX = _m["kernels"] if _m.get("kernel_sources_sha") in (None, kernel_sources_sha()) else {}
-    if not ISA_MIX: print("profiles/r05_isa_mix.json was made on other kernel sources: no valu_issue fraction (rerun scripts/isa_mix.py)", file=sys.stderr)
+    if not ISA_MIX: print("profiles/r0N_isa_mix.json was made on other kernel sources: no valu_issue fraction (rerun scripts/isa_mix.py)", file=sys.stderr)
 except Exception:
     ISA_MIX = {}
 if RECORDED_SHA and RECORDED_SHA != kernel_sources_sha():
@@ -68,7 +69,7 @@ for k, c in ctr.items():
                            "frac_probe_rates": need_probe / (SIMDS * cyc),
                            "wave_instructions_by_class": cls,
                            "avg_issue_cycles_by_class": {k: round(mix.get(k, {}).get("avg_issue_cycles", 4.3), 3) for k in cls},
-                           "source": "class counters of this profile x profiles/r05_isa_mix.json (opcode rates: profiles/r04_valu_classes.json)"}
+                           "source": "class counters of this profile x profiles/r06_isa_mix.json (opcode rates: profiles/r04_valu_classes.json)"}
     if g("SQ_THREAD_CYCLES_VALU") is not None and g("SQ_ACTIVE_INST_VALU"): d["lanes_enabled_per_valu_fraction"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"): d["lds_conflict_share_of_lds_cycles"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     if g("SQ_LDS_IDX_ACTIVE") is not None and cyc: d["lds_pipe_busy_fraction"] = g("SQ_LDS_IDX_ACTIVE") / (256.0 * cyc)

@@ -46,7 +46,22 @@ probe.sync()
 one = dict(bin=probe.last_kernel_ms(0), fill=probe.last_kernel_ms(1), rm=probe.last_kernel_ms(2), samples=probe.stats()["samples"])
 zb = probe.z_boundary(cam)
 ref = img.clone()
+BIG = sc.N[2] > 32
+if BIG:
+    # the per-slice cost profile the planner cuts from (what a fan-out context measures in its warm-up: pairs per slice for the fill, executed
+    # samples per slice for the ray-march, scaled to the measured kernel times): taken from the ONE whole-grid context, because N slab contexts of
+    # config 5 with their allocation head-room do not fit one GPU together
+    hist = np.asarray(probe.z_histogram(), dtype=np.float64)
+    probe.bin_resident(); probe.fill(sc.fill_params())           # (the histogram pass re-bins: the bricks count as stale until the next fill)
+    o_, u_ = torch.empty_like(img), torch.empty_like(img)
+    probe.raymarch_partial_handoff_device(cam, rp, o_.data_ptr(), u_.data_ptr(), 0, 0, 0, 0)
+    probe.sync()
+    zs = np.asarray(probe.zsamples(), dtype=np.float64)
+    fill_w = list(hist / max(hist.sum(), 1.0) * one["fill"])
+    rm_w = list(zs / max(zs.sum(), 1.0) * one["rm"])
+    del o_, u_
 probe.close()
+torch.cuda.empty_cache()
 one_ms = one["bin"] + one["fill"] + one["rm"]
 print(f"1 GPU: bin {one['bin']:.3f} fill {one['fill']:.3f} ray-march {one['rm']:.3f} = {one_ms:.3f} ms, {one['samples'] / 1e6:.0f} M samples, zBoundary {zb}")
 npix = sc.width * sc.height
@@ -62,26 +77,35 @@ def frame(e, first=False):
     e.bin_resident(); e.fill(sc.fill_params()); e.raymarch_device(cam, rp, img.data_ptr())
 
 
-BIG = sc.N[2] > 32
 for world in ((2, 4, 8) if BIG else (2, 4, 7, 8)):                # (7: the slab cut of the alternative 8-GPU plan below)
-    for groups in ([1, 2] if BIG else sorted({1, 2, world}) if world != 7 else [1]):
-        # 1. the library's own cut, chain and groups
-        m = E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY, rm_groups=groups))
-        m.set_frame(sc.light_to_world, sc.grid_center)
-        m.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
-        frame(m)
-        for _ in range(2):
-            m.rebalance(); frame(m)
-        frame(m)                       # (the cut asked for by the second vp_rebalance takes effect at this frame's bin)
-        m.sync()
-        err = float((img - ref).abs().max().item())
-        info = m.multi_info()
-        m.close()
-        torch.cuda.empty_cache()
-        cuts, chain, group_of = info["slab_cuts"], info["chain"], info["group_of"]
+    for groups in ([1] if BIG else sorted({1, 2, world}) if world != 7 else [1]):
+        if BIG:
+            # 1'. the library's planner on the whole-grid context's cost profile (see above); no hand-off groups
+            bounds = E.plan_slabs(sc.N[2], world, fill_ms=fill_w, rm_ms=rm_w, rm_groups=1)
+            cuts = [b[0] for b in bounds] + [bounds[-1][1]]
+            chain = E.blend_plan(bounds, zb)[0]
+            group_of = [0] * world
+            err = float("nan")
+        else:
+            # 1. the library's own cut, chain and groups
+            m = E.Engine(sc.config(devices=[0] * world, multi_flags=abi.VP_MULTI_PEER_COPY, rm_groups=groups))
+            m.set_frame(sc.light_to_world, sc.grid_center)
+            m.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
+            frame(m)
+            for _ in range(2):
+                m.rebalance(); frame(m)
+            frame(m)                       # (the cut asked for by the second vp_rebalance takes effect at this frame's bin)
+            m.sync()
+            err = float((img - ref).abs().max().item())
+            info = m.multi_info()
+            m.close()
+            torch.cuda.empty_cache()
+            cuts, chain, group_of = info["slab_cuts"], info["chain"], info["group_of"]
         # 2. every slab alone on the GPU, front to back, with the real hand-off maps
         rows, maps = {}, {}
         for r in chain:
+            torch.cuda.empty_cache()
+            free0 = torch.cuda.mem_get_info()[0]
             e = E.Engine(sc.config(device=0, slab=(cuts[r], cuts[r + 1])))
             e.set_frame(sc.light_to_world, sc.grid_center)
             e.upload_particles(sc.particles, sc.layout, sc.psys_local_to_world)
@@ -99,9 +123,10 @@ for world in ((2, 4, 8) if BIG else (2, 4, 7, 8)):                # (7: the slab
                                                   t_out[0].data_ptr(), t_out[1].data_ptr())
             e.sync()
             st = e.stats()
+            device_bytes = free0 - torch.cuda.mem_get_info()[0]      # everything this rank holds: bricks + scratch + CSR + images + the all-gathered maps
             maps[r] = (t_out[0].clone(), t_out[1].clone())
             rows[r] = dict(slab=[cuts[r], cuts[r + 1]], group=group_of[r], bin=e.last_kernel_ms(0), fill_local=e.last_kernel_ms(1), finish=e.last_kernel_ms(3) if r else 0.0,
-                           rm=e.last_kernel_ms(2), samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"], brick_bytes=st["brick_bytes"])
+                           rm=e.last_kernel_ms(2), samples=st["samples"], occupied=st["occupied_mv"], pairs=st["pairs"], brick_bytes=st["brick_bytes"], device_bytes=int(device_bytes))
             e.close(); del tau_all, over, under
             torch.cuda.empty_cache()
         # 3. the pipeline
@@ -132,7 +157,8 @@ for world in ((2, 4, 8) if BIG else (2, 4, 7, 8)):                # (7: the slab
         print(f"N={world} groups={groups}: predicted {t * 1e3:.2f} ms/step ({one_ms / (t * 1e3):.2f}x; serial schedule {t_serial * 1e3:.2f}); cut {cuts}; "
               f"max bin+fill_local {max(x['bin'] + x['fill_local'] for x in rows.values()):.2f} finish {max(x['finish'] for x in rows.values()):.2f} max finish+rm {max(x['finish'] + x['rm'] for x in rows.values()):.2f} "
               f"rm per group {[round(x, 3) for x in rm_groups]} (max single {max(x['rm'] for x in rows.values()):.3f}); exchanges {1e3 * (t_tau + (G - 1) * t_hop + t_img):.2f}; "
-              f"samples {sum(x['samples'] for x in rows.values()) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M; fan-out image err {err:.1e}", flush=True)
+              f"samples {sum(x['samples'] for x in rows.values()) / 1e6:.0f} M vs {one['samples'] / 1e6:.0f} M; fan-out image err {err:.1e}; "
+              f"largest rank holds {max(x['device_bytes'] for x in rows.values()) / 2**30:.1f} GiB", flush=True)
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # ONE alternative plan for 8 GPUs: the front slab -- the one that holds most of the ray-march when light and camera are on
 # the same side -- is FILLED ON TWO RANKS (replicated: each fills the whole slab) which split its SCREEN, so that its ray-march halves; the other

@@ -7,6 +7,8 @@ form, hand-off groups, a re-cut) and the UNORM8 render-target emulation; every s
 
   * seeds 1000 .. 1199: the scenes of the sweeps of rounds 2-4 (voxel counts 16 / 32 / 64);
   * seeds 1 000 000 .. 1 000 219: the second generation -- any numVoxelsInMetavoxel in [2, 64], odd ones included (the run-time-nv kernels);
+  * seeds 3 000 000 .. 3 000 099: the third generation (round 6) -- opaque solids (boxes, capped cylinders, ellipsoids: vp_set_occluders2) in 60 % of
+    the scenes: both depth inputs rendered from them on the GPU must EQUAL the oracle's (same fp32 operation order), then everything above;
   * the seeds that once failed, by name.
 (Development runs of several thousand scenes per round are kept as one-line tails under profiles/.)"""
 import importlib.util
@@ -46,7 +48,7 @@ def test_regression_seed(seed):
     assert r["rgba_err"] <= 1e-3, (seed, REGRESSION_SEEDS[seed])
 
 
-@pytest.mark.parametrize("first", list(range(1000, 1200, 10)) + list(range(1_000_000, 1_000_220, 10)))
+@pytest.mark.parametrize("first", list(range(1000, 1200, 10)) + list(range(1_000_000, 1_000_220, 10)) + list(range(3_000_000, 3_000_100, 10)))
 def test_random_scenes(first):
     fz = _fuzz()
     for seed in range(first, first + 10):

@@ -388,7 +388,10 @@ def test_fanout_at_the_extremes_of_the_frame_parameters(case, world, flags):
     D = 0.8 * sc.N[0] * sc.mv_scale
     if case == "odd_voxels_with_occluders":
         boxes = [S.make_box((0.0, -0.2 * D, 0.0), (2.0 * D, 0.02 * D, 2.0 * D)),
-                 S.make_box((0.15 * D, 0.1 * D, -0.3 * D), (0.1 * D, 0.12 * D, 0.1 * D), S.quat_to_matrix((0.2, -0.1, 0.3, 0.927)).T)]
+                 S.make_box((0.15 * D, 0.1 * D, -0.3 * D), (0.1 * D, 0.12 * D, 0.1 * D), S.quat_to_matrix((0.2, -0.1, 0.3, 0.927)).T),
+                 # ABI 6: typed solids reach every slab context through vp_set_occluders2
+                 S.make_solid(abi.VP_OCC_CYLINDER, (-0.2 * D, 0.0, -0.25 * D), (0.06 * D, 0.3 * D, 0.06 * D)),
+                 S.make_solid(abi.VP_OCC_ELLIPSOID, (0.0, 0.15 * D, -0.35 * D), (0.12 * D, 0.05 * D, 0.08 * D), S.quat_to_matrix((0.1, 0.5, -0.2, 0.837)).T)]
 
     def frame(eng):
         eng.set_frame(sc.light_to_world, sc.grid_center)

@@ -66,6 +66,11 @@ static __device__ unsigned long long g_fill_prof[12];    // (the run-time-nv ker
 #ifndef VPFX_FILL_LDS_WAVES
 #define VPFX_FILL_LDS_WAVES 16  // waves of the persistent workgroup (one per CU): 16 = 4 per SIMD (<= 128 VGPRs; measured 8 / 12 / 16 waves: 4.00 / 3.61 / 3.56 ms at C3)
 #endif
+// ... and of the run-time-voxel-count instantiations (GEN): at 16 waves (128-VGPR cap) they spill 3-13 VGPRs (16-56 B of scratch per lane);
+// 12 waves (168 VGPRs) hold everything in registers.  Measured at C3nv24 (32^3 x 24^3, round 6): see PERFLOG.
+#ifndef VPFX_FILL_LDS_WAVES_GEN
+#define VPFX_FILL_LDS_WAVES_GEN 16
+#endif
 // units per global-counter atomic of the persistent LDS kernel (workgroup-level claim, see k_fill_lds); 1 = one device-scope atomic per unit (A/B)
 #ifndef VPFX_FILL_CLAIM
 #define VPFX_FILL_CLAIM 16
@@ -275,9 +280,6 @@ __device__ __forceinline__ unsigned cube_address(const FillConsts& f, float psx,
 #ifndef VPFX_BYTE_DENORM
 #define VPFX_BYTE_DENORM 1
 #endif
-#ifndef VPFX_SMOOTH_SKIP
-#define VPFX_SMOOTH_SKIP 0
-#endif
 template <bool EXACT, bool DONE, bool BYTES = false>
 __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_D /* in a VGPR: an FMA reads one SGPR only */,
                                            const float4 q /* (t00, t01, t10, t11) */, float tx, float ty,
@@ -294,18 +296,6 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
     }
     const float raw = fmaf(ty, b - a, a);
     net = fmaf(Dk, raw, one_minus_D);                                             // netDisplacement   :119
-#if VPFX_SMOOTH_SKIP
-    // A/B (VERDICT r5 next #6a; PERFLOG round 6): wave-uniform smoothstep skip.  smoothstep(net, 0.7 net, 4 d2) is exactly 1 where
-    // 4 d2 <= 0.7 net (the sphere's core) and exactly 0 where 4 d2 >= net; when EVERY covered lane of the wave-slice is in the core (or every
-    // one outside the displaced surface) the reciprocal, the clamped FMA and the cubic are skipped.  Margins (0.69 / 1.01) keep the skipped
-    // lanes where the fast path's t, computed with v_rcp_f32, clamps to exactly 1 / 0: bit-identical to the build without the skip.
-    // (called inside `if (hit)`: the ballot sees the covered lanes only)
-    if (!EXACT && !DONE) {
-        const float d2q = 4.0f * d2;
-        if (__builtin_amdgcn_ballot_w64(d2q > 0.69f * net) == 0) { const float k = f.opacity_factor * opw; den = fmaf(1.0f, -2.0f * k, 3.0f * k); return; }
-        if (__builtin_amdgcn_ballot_w64(d2q < 1.01f * net) == 0) { den = 0.f; return; }
-    }
-#endif
     float t;
     if (EXACT) {
         const float d2q = 4.0f * d2;                                              // dot(2ps, 2ps)     :121
@@ -339,6 +329,22 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
         const float k = f.opacity_factor * opw;
         den = (t * t) * fmaf(t, -2.0f * k, 3.0f * k);
     }
+}
+
+// One 8-byte brick entry.  VPFX_NT_BRICKS: stored with the non-temporal hint -- the bricks stream out once per fill (2.8 GB at C3, 168 GB at C5, far
+// beyond the 32 MB of L2) and are next read by the ray-march long after; as normal stores they push the kernel's small re-used state out of L2:
+// the per-wave scratch of the spilled registers (nv = 64: 18 VGPRs = 76 B per lane and unit), the hand-off words, the particle records
+// (round 6, EA request counters at C5: 25 GB of scratch written back and 25 GB re-fetched per fill).
+#ifndef VPFX_NT_BRICKS
+#define VPFX_NT_BRICKS 0
+#endif
+__device__ __forceinline__ void store_brick(uint2* p, uint32_t lo, uint32_t hi)
+{
+#if VPFX_NT_BRICKS
+    __builtin_nontemporal_store((unsigned long long)lo | ((unsigned long long)hi << 32), reinterpret_cast<unsigned long long*>(p));
+#else
+    *p = make_uint2(lo, hi);
+#endif
 }
 
 // Chained fill.  The unit of work of the persistent kernel is ONE metavoxel of one 8x8-column tile, not the tile's whole walk along the
@@ -652,13 +658,13 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         if (GREYB) {
                             // entry(z) = texel(z), texel(z + 1): stored one slice late, when the slice behind it is known
                             const uint32_t cur = pack_half2(cr, dens[s]);
-                            if (owns && sg > 0) brick[vi - (size_t)nv * nv] = make_uint2(prev_texel, cur);
-                            if (owns && sg == nv - 1) brick[vi] = make_uint2(cur, cur);  // (the last slice is never a footprint's z0)
+                            if (owns && sg > 0) store_brick(brick + (vi - (size_t)nv * nv), prev_texel, cur);
+                            if (owns && sg == nv - 1) store_brick(brick + vi, cur, cur);   // (the last slice is never a footprint's z0)
                             prev_texel = cur;
                         } else {
                             const float cg = 0.4f * T + f.amb[1] * ao[s];
                             const float cb = 0.4f * T + f.amb[2] * ao[s];
-                            if (owns) brick[vi] = make_uint2(pack_half2(cr, cg), pack_half2(cb, dens[s]));
+                            if (owns) store_brick(brick + vi, pack_half2(cr, cg), pack_half2(cb, dens[s]));
                         }
                     } else {
                         if (owns) scratch[vi] = make_float2(dens[s], ao[s]);
@@ -721,7 +727,7 @@ k_fill(GridConsts g, FillConsts f, FILL_PTR_PARAMS, FillChain ch, int* __restric
 // One PERSISTENT workgroup of 16 waves per CU (4 per SIMD) loads the table once; every wave then pulls (metavoxel, 8x8-column tile)
 // units from a global work counter on its own.
 template <int NV, int MODE, int TAB, bool DONE, bool GEN = false>
-__global__ void __launch_bounds__(64 * VPFX_FILL_LDS_WAVES)
+__global__ void __launch_bounds__(64 * (GEN ? VPFX_FILL_LDS_WAVES_GEN : VPFX_FILL_LDS_WAVES))
 k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restrict__ p_cube_u8, int table_dwords, int* __restrict__ p_counter,
            int nitems, FillChain ch, int claim_log2)
 {
@@ -734,7 +740,7 @@ k_fill_lds(GridConsts g, FillConsts f, FILL_PTR_PARAMS, const uint32_t* __restri
     __syncthreads();
     if (threadIdx.x == 0) s_block[0] = (1ull << 32) | (unsigned)atomicAdd(p_counter, 1 << claim_log2);     // block 0 (in flight during the table copy)
 #endif
-    for (int i = threadIdx.x; i < table_dwords; i += 64 * VPFX_FILL_LDS_WAVES) lds_cube[i] = p_cube_u8[i];
+    for (int i = threadIdx.x; i < table_dwords; i += 64 * (GEN ? VPFX_FILL_LDS_WAVES_GEN : VPFX_FILL_LDS_WAVES)) lds_cube[i] = p_cube_u8[i];
     __syncthreads();
     const unsigned lds_base = (unsigned)(size_t)lds_cube;       // low half of the flat address of an LDS object = its LDS byte offset
     const int T8 = GEN ? (g.nv + 7) >> 3 : NV / 8, TPC = T8 * T8; // 8x8-column tiles per MV column
@@ -943,8 +949,8 @@ int launch_fill_lds_variant(vp_ctx* c, const FillPtrs& P)
     const int nitems = c->h_meta.occupied * TPC;
     { int rc = chain_begin(c, P, MODE, ch); if (rc) return rc; }
     if (nitems == 0) return VP_OK;
-    constexpr int WV = VPFX_FILL_LDS_WAVES;
-    static_assert(VPFX_FILL_CLAIM == 1 || VPFX_FILL_CLAIM == WV, "a full block is one unit per wave of the workgroup");
+    constexpr int WV = GEN ? VPFX_FILL_LDS_WAVES_GEN : VPFX_FILL_LDS_WAVES;
+    static_assert(VPFX_FILL_CLAIM == 1 || VPFX_FILL_CLAIM >= WV, "a full block holds a unit for every wave of the workgroup (tickets are drawn as waves come free)");
     // units per block = working waves per workgroup: the full 16 once there is a block for every CU, else halved until there is (at least
     // 4 = one wave per SIMD).  Measured (profiles/r04_ab/fill_small_launches_spread_over_all_cus.txt): DEMO / C1 have 1 248 units; blocks of
     // 16 / 8 / 4 / 2 / 1 -> fill 0.128 / 0.092 / 0.090 / 0.116 / 0.147 ms (DEMO), 0.085 / 0.070 / 0.070 / 0.094 / 0.126 (C1); bit-identical bricks.

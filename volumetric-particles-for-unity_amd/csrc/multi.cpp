@@ -654,8 +654,15 @@ int multi_create(const vp_config* cfg, vp_ctx** out)
         one.slab_z0 = M->cuts[k.rank]; one.slab_z1 = M->cuts[k.rank + 1];
         int rc = vp_create_single(&one, &k.c);
         if (rc) return fail(rc, "slab context");
-        if (hipSetDevice(k.device) != hipSuccess || hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&k.xstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&k.ev_local, hipEventDisableTiming) != hipSuccess ||
+        // The exchange stream gets the device's HIGHEST priority: the all-gather of the transmittance maps is launched while the first slab's
+        // ray-march fills every CU (the planner counts on the two running side by side: host_logic.cpp, two_maxima_partition); at equal priority
+        // its kernel could queue behind the march's remaining workgroups and hold back every other rank's finish pass.  With a higher
+        // priority the dispatcher hands it the first CUs that free up.  (No priorities on the device: lo == hi, a plain stream.)
+        int prio_lo = 0, prio_hi = 0;
+        if (hipSetDevice(k.device) != hipSuccess) return fail(VP_ERR_HIP, "hipSetDevice");
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_lo = prio_hi = 0; }
+        if (hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithPriority(&k.xstream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipEventCreateWithFlags(&k.ev_local, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&k.ev_tau, hipEventDisableTiming) != hipSuccess) return fail(VP_ERR_HIP, "hipStreamCreate");
         k.c->stream = k.stream;
         const size_t img = M->pixpad * 4, plane = M->npix;

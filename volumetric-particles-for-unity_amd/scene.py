@@ -23,6 +23,8 @@ CONFIGS = {
     "C2": (16, 32, 10_000, 1280, 720),
     "C3": (32, 32, 100_000, 1920, 1080),
     "C5": (64, 64, 1_000_000, 3840, 2160),
+    # C3's grid, particles and screen with a voxel count that is none of 16 / 32 / 64: the run-time-nv ("generic") kernels on the benchmark's scale
+    "C3nv24": (32, 24, 100_000, 1920, 1080),
     # small extras used by tests
     "T0": (4, 16, 120, 96, 64),
     "T1": (6, 32, 400, 160, 120),
