@@ -331,20 +331,18 @@ __device__ __forceinline__ void cube_shade(const FillConsts& f, float one_minus_
     }
 }
 
-// One 8-byte brick entry.  VPFX_NT_BRICKS: stored with the non-temporal hint -- the bricks stream out once per fill (2.8 GB at C3, 168 GB at C5, far
-// beyond the 32 MB of L2) and are next read by the ray-march long after; as normal stores they push the kernel's small re-used state out of L2:
-// the per-wave scratch of the spilled registers (nv = 64: 18 VGPRs = 76 B per lane and unit), the hand-off words, the particle records
-// (round 6, EA request counters at C5: 25 GB of scratch written back and 25 GB re-fetched per fill).
-#ifndef VPFX_NT_BRICKS
-#define VPFX_NT_BRICKS 0
-#endif
+// One 8-byte brick entry.  NT: stored with the non-temporal hint -- the bricks stream out once per fill (2.8 GB at C3, 168 GB at C5, far beyond
+// the 32 MB of L2) and are next read by the ray-march long after; as normal stores they push the kernel's small re-used state out of L2: the
+// per-wave scratch of the spilled registers, the hand-off words, the particle records.  Measured in round 6 (EA request counters, PERFLOG):
+//   nv = 64 (k_fill_lds<64> spills 18 VGPRs = 76 B per lane and unit: 25 GB of scratch written back and re-fetched per C5 fill):
+//           traffic 244 -> 199 GB per launch (1.43x -> 1.16x of the algorithmic bytes), fill 166.5 -> 165.3 ms -- taken;
+//   nv = 32: the builtin (and the same instruction as inline asm) perturbs register allocation of the 32-slice store loop (scratch 12 -> 376 /
+//           156 B per lane) and the fill is 5-7 % SLOWER -- not taken: the nv <= 32 and the run-time-nv kernels keep the plain store.
+template <bool NT>
 __device__ __forceinline__ void store_brick(uint2* p, uint32_t lo, uint32_t hi)
 {
-#if VPFX_NT_BRICKS
-    __builtin_nontemporal_store((unsigned long long)lo | ((unsigned long long)hi << 32), reinterpret_cast<unsigned long long*>(p));
-#else
-    *p = make_uint2(lo, hi);
-#endif
+    if constexpr (NT) __builtin_nontemporal_store((unsigned long long)lo | ((unsigned long long)hi << 32), reinterpret_cast<unsigned long long*>(p));
+    else *p = make_uint2(lo, hi);
 }
 
 // Chained fill.  The unit of work of the persistent kernel is ONE metavoxel of one 8x8-column tile, not the tile's whole walk along the
@@ -645,6 +643,7 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
             // The format is wave-uniform: the branch is taken once per chunk, outside the 32 unrolled slices.
             auto propagate_store = [&](auto grey_tag) {
                 constexpr bool GREYB = decltype(grey_tag)::value;
+                constexpr bool NT_BRICKS = NV == 64 && !GEN;                             // see store_brick
 #pragma unroll
                 for (int s = 0; s < CH; ++s) {
                     const int sg = c0 + s;
@@ -658,13 +657,13 @@ __device__ __forceinline__ void fill_tile(const GridConsts& g, const FillConsts&
                         if (GREYB) {
                             // entry(z) = texel(z), texel(z + 1): stored one slice late, when the slice behind it is known
                             const uint32_t cur = pack_half2(cr, dens[s]);
-                            if (owns && sg > 0) store_brick(brick + (vi - (size_t)nv * nv), prev_texel, cur);
-                            if (owns && sg == nv - 1) store_brick(brick + vi, cur, cur);   // (the last slice is never a footprint's z0)
+                            if (owns && sg > 0) store_brick<NT_BRICKS>(brick + (vi - (size_t)nv * nv), prev_texel, cur);
+                            if (owns && sg == nv - 1) store_brick<NT_BRICKS>(brick + vi, cur, cur);   // (the last slice is never a footprint's z0)
                             prev_texel = cur;
                         } else {
                             const float cg = 0.4f * T + f.amb[1] * ao[s];
                             const float cb = 0.4f * T + f.amb[2] * ao[s];
-                            if (owns) store_brick(brick + vi, pack_half2(cr, cg), pack_half2(cb, dens[s]));
+                            if (owns) store_brick<NT_BRICKS>(brick + vi, pack_half2(cr, cg), pack_half2(cb, dens[s]));
                         }
                     } else {
                         if (owns) scratch[vi] = make_float2(dens[s], ao[s]);
