@@ -187,3 +187,24 @@ def test_a_rank_that_dies_mid_run_ends_the_job_nonzero_instead_of_hanging():
     assert took < 300, took
     assert not any(l.startswith("{") for l in r.stdout.splitlines()), r.stdout[-2000:]
     assert "TEST HOOK: rank 1 leaves the job" in r.stderr
+
+
+def test_config5_shape_through_the_drivers_command_at_eight_ranks():
+    """BASELINE config 5's SHAPE through `bench.py --gpus 8` as the driver launches it (VERDICT r5 next #1c): 64^3-voxel bricks, the 3840 x 2160 screen (133 MB
+    partial images, 16.6 MB exchange pieces), eight processes.  Eight ranks of the full 64^3-metavoxel grid need 8 x 25-50 GiB (profiles/r06_scaling_model_C5_r8.json)
+    and cannot share one 288-GB test GPU, so the grid is one eighth of config 5's (32^3 metavoxels, 125 k particles: 'C5e'); the full grid's sharded parity is
+    tests/test_gpu_large_configs.py::test_config5_through_the_fanout_slab_by_slab."""
+    _build_mp_shim()
+    cmd = _driver_command(8, _free_port(), steps=4, warmup=3) + ["--config", "C5e"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_driver_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-3000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["workload"].startswith("C5e: 32x32x32 metavoxels x 64^3 voxels")
+    assert len(c["slabs"]) == 8 and c["slabs"][0][0] == 0 and c["slabs"][-1][1] == 32
+    assert c["max_abs_rgba_diff_vs_1gpu_frame"] is not None and c["max_abs_rgba_diff_vs_1gpu_frame"] <= 2e-5
+    pr = d["per_rank"]
+    assert len(pr["samples"]) == 8 and all(row[1] > 0 for row in pr["kernel_ms_bin_fill_raymarch_finish"])
+    assert d["roofline_all"]["fill"]["kernel"] == "k_fill_lds" and d["value"] > 0

@@ -25,6 +25,8 @@ CONFIGS = {
     "C5": (64, 64, 1_000_000, 3840, 2160),
     # C3's grid, particles and screen with a voxel count that is none of 16 / 32 / 64: the run-time-nv ("generic") kernels on the benchmark's scale
     "C3nv24": (32, 24, 100_000, 1920, 1080),
+    # one eighth of config 5's metavoxels at config 5's voxel count and screen: what EIGHT ranks sharing one test GPU can hold (bench.py --gpus 8 on the stand-in)
+    "C5e": (32, 64, 125_000, 3840, 2160),
     # small extras used by tests
     "T0": (4, 16, 120, 96, 64),
     "T1": (6, 32, 400, 160, 120),
