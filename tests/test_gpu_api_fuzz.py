@@ -54,6 +54,10 @@ def _ops(sc, rng, boxes):
         "sync": lambda e: e.sync(),
         "occluders_on": lambda e: e.set_occluders(boxes),
         "occluders_off": lambda e: e.set_occluders([]),
+        "solids_on": lambda e: e.set_occluders(boxes + [S.make_solid(abi.VP_OCC_CYLINDER, (0.0, 0.0, 0.0), (0.5, 1.0, 0.5)),
+                                                        S.make_solid(abi.VP_OCC_ELLIPSOID, (1.0, 0.5, -1.0), (0.8, 0.4, 0.6))]),     # ABI 6: vp_set_occluders2
+        "solids_bad": lambda e: e.set_occluders([S.make_solid(int(rng.choice([-1, 3, 99])), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+                                                 if rng.random() < 0.5 else S.make_solid(abi.VP_OCC_CYLINDER, (0.0, 0.0, 0.0), (1.0, float(rng.choice([0.0, -1.0, np.nan])), 1.0))]),
         "rebalance": lambda e: e.rebalance(),
         "last_ms": lambda e: e.last_kernel_ms(int(rng.integers(-1, 5))),
     }
