@@ -260,3 +260,41 @@ def test_csharp_frame_runs_the_references_callbacks():
     structs = cs_structs(open(CS).read())
     assert flatten_cs(structs, "vp_occluder") == flatten_ct(abi.vp_occluder)
     assert C.sizeof(abi.vp_occluder) == 64 and C.sizeof(abi.vp_obb) == 60
+
+
+def test_csharp_sources_are_lexically_well_formed():
+    """No C# compiler here: the least a source-only file owes its reader is balanced delimiters outside strings / comments, every method the frame calls
+    defined exactly once, and no identifier used by the frame that is declared nowhere in the file (a cheap stand-in for 'it parses')."""
+    for path in (CS, os.path.join(os.path.dirname(CS), "VpfxCopyDepth.shader")):
+        src = open(path).read()
+        # strip comments, then string / char literals
+        code = re.sub(r'"(\\.|[^"\\])*"', '""', strip_comments(src))
+        code = re.sub(r"'(\\.|[^'\\])'", "''", code)
+        stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+        for i, ch in enumerate(code):
+            if ch in "([{":
+                stack.append((ch, i))
+            elif ch in ")]}":
+                assert stack and stack[-1][0] == pairs[ch], f"{os.path.basename(path)}: unbalanced {ch!r} near ...{code[max(0, i - 60):i + 1]!r}"
+                stack.pop()
+        assert not stack, f"{os.path.basename(path)}: unclosed {stack[-1][0]!r} near ...{code[stack[-1][1]:stack[-1][1] + 60]!r}"
+    src = strip_comments(open(CS).read())
+    methods = cs_methods(open(CS).read())
+    # every helper the frame calls exists once
+    for name in ("SyncOccluders", "ReadBackDepthTextures", "ReadDepth", "LightDepthMapPtr", "SceneDepthPtr", "CompositeParticles", "CreateSceneTargets", "PlaceLightCamera",
+                 "FillParams", "CameraAndParams", "ParticleLayout", "IssueFrameOnRenderThread"):
+        assert len(re.findall(r"\b(?:void|IntPtr|vp_\w+)\s+" + name + r"\s*\(", src)) == 1, name
+    # fields the new frame code uses are declared
+    for field in ("mainSceneRT", "lightDepthMap", "lightCamera", "lightDepth", "sceneDepth", "lightDepthHandle", "sceneDepthHandle", "lightDepthTex", "sceneDepthTex",
+                  "occluderHash", "occludersSent", "matBlendParticles", "generateLightDepthMapShader", "copyDepthMaterial", "occluderSource"):
+        decl = re.search(r"\b(?:public\s+)?(?:RenderTexture|GameObject|float\[\]|GCHandle|Texture2D|int|bool|Material|Shader|OccluderSource)\s+[\w\s,=]*\b" + field + r"\b", src)
+        assert decl, f"field {field} is used but not declared"
+    # statements inside method bodies end in ';' or a block: no line that ends in an identifier / ')' followed by a line starting a new statement keyword
+    for name, body in methods.items():
+        for m in re.finditer(r"[\w\)\]]\s*\n\s*(?:var|int|float|bool|if|for|foreach|return|Check|vp_\w+)\b", body):
+            ctx = body[max(0, m.start() - 80):m.end() + 20]
+            # allowed: a line break inside an argument list / initializer (open delimiter before the break)
+            before = body[:m.start() + 1]
+            depth = before.count("(") - before.count(")") + before.count("[") - before.count("]")
+            brace_init = re.search(r"(new\s+[\w<>\[\]]+\s*(\([^()]*\))?\s*\{[^{}]*|else|\))\s*$", before) is not None
+            assert depth > 0 or brace_init or before.rstrip().endswith(("else", ")")), f"{name}: statement seems to lack a terminator near {ctx!r}"
