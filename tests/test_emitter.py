@@ -149,10 +149,14 @@ def test_bad_arguments_are_refused():
     h = C.c_void_p()
     assert L.vp_emitter_create(None, C.byref(h)) == abi.VP_ERR_BAD_ARG
     for field, value in (("lifetime", 0.0), ("cone_radius", 0.0), ("cone_angle_deg", 90.0), ("rate", -1.0), ("max_particles", -1), ("size", 0.0),
-                         ("speed", float("nan"))):
+                         ("speed", float("nan")), ("lifetime", float("inf")), ("lifetime", 1.0e30), ("lifetime", float("nan")), ("rate", float("inf"))):
         cfg = default_cfg()
         setattr(cfg, field, value)
         assert L.vp_emitter_create(C.byref(cfg), C.byref(h)) == abi.VP_ERR_BAD_ARG and not h.value, field
+    #  an unbounded lifetime with prewarm used to mean lifetime x 30 simulation steps inside vp_emitter_create: refused before any step runs
+    cfg = default_cfg()
+    cfg.lifetime, cfg.reserved[0] = float("inf"), 1
+    assert L.vp_emitter_create(C.byref(cfg), C.byref(h)) == abi.VP_ERR_BAD_ARG and not h.value
     em = S.DemoEmitter()
     assert L.vp_emitter_step(em.h, C.c_float(-0.1)) == abi.VP_ERR_BAD_ARG
     assert L.vp_emitter_step(em.h, C.c_float(float("inf"))) == abi.VP_ERR_BAD_ARG

@@ -65,3 +65,23 @@ def test_the_standin_reports_what_hangs_on_rccl_and_failure_paths_of_the_fanout(
     passed, st, tail = run_child(["tests/tools/rccl_shim_cases.py"], tmp_path, timeout=600)
     assert passed == 8 + 3, tail
     assert st["errors"] >= 8 and st["aborts"] >= 1, st              # every negative case was reported by the stand-in; the injected fault aborted
+
+
+def test_an_unloadable_rccl_library_is_an_error_code_not_a_crash():
+    """VPFX_RCCL_LIBRARY pointing at something dlopen() refuses must come back from vp_create as VP_ERR_RCCL with dlopen's reason in the
+    message (the message used to be built from a second dlerror() call, which returns NULL: undefined behaviour).  Child process: the loader's verdict is
+    cached per process."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from __graft_entry__ import load_package; load_package()\n"
+            "from vpfx_amd import abi, engine as E, scene as S\n"
+            "sc = S.make_scene('T0')\n"
+            "try:\n"
+            "    E.Engine(sc.config(devices=[0, 0], multi_flags=abi.VP_MULTI_TEST_HOOKS | abi.VP_MULTI_TEST_SHARED_DEVICE))\n"
+            "    print('CREATED')\n"
+            "except E.VpfxError as ex:\n"
+            "    print('CODE', ex.code, str(ex))\n") % ROOT
+    env = dict(os.environ, VPFX_RCCL_LIBRARY="/nonexistent/librccl_not_here.so")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "CODE -7" in r.stdout and "VPFX_RCCL_LIBRARY=/nonexistent/librccl_not_here.so cannot be loaded" in r.stdout, r.stdout[-2000:]
+    assert "No such file" in r.stdout or "cannot open shared object" in r.stdout, r.stdout[-2000:]
