@@ -1,8 +1,8 @@
-# hunt a 1-in-5 failure of the driver-command tests: loop them, keep the output of every failing pass
+# hunt a rare failure of the rank-dies-mid-run test seen once in a full-suite pass: the suite's prefix up to it, looped; output of every failing pass kept
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r6_flaky
-for i in $(seq 1 ${N:-15}); do
-  timeout 900 python -m pytest tests/test_gpu_bench_cli.py -x -q -m gpu -k "drivers_scaling or dies_mid_run or config5_shape or multiprocess_standin" > /tmp/pass_$i.log 2>&1
+for i in $(seq 1 ${N:-20}); do
+  timeout 900 python -m pytest tests/test_c_abi.py tests/test_gpu_api_fuzz.py tests/test_gpu_bench_cli.py -x -q -m gpu > /tmp/pass_$i.log 2>&1
   rc=$?
   echo "pass $i rc=$rc $(grep -E 'passed|failed' /tmp/pass_$i.log | tail -1)"
   [ $rc -ne 0 ] && cp /tmp/pass_$i.log gpurun_out/r6_flaky/pass_$i.log

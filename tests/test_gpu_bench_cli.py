@@ -101,15 +101,12 @@ def test_one_process_per_gpu_launch_runs_to_its_json_line_on_the_multiprocess_st
     at tests/tools/fake_rccl_mp.cpp, which stages the bytes through a shared segment between the processes under RCCL's matching rules.  Checked:
     one JSON line from rank 0 with the contract's keys, N RCCL ranks, the library's slab cut, per-rank figures from every process, and the sharded
     frame equal to the 1-GPU frame rendered on rank 0 before the timed region."""
-    import socket
     _build_mp_shim()
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, MASTER_ADDR="127.0.0.1",
-               VPFX_RCCL_LIBRARY=MP_SHIM, FAKE_RCCL_TIMEOUT_MS="60000")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-gpu", "--config", "C1", "--steps", "4",
-                        "--warmup", "2", "--exchange", exchange],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+               VPFX_RCCL_LIBRARY=MP_SHIM, FAKE_RCCL_TIMEOUT_MS="120000")
+    r = _run_driver(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-gpu", "--config", "C1", "--steps", "4",
+                                  "--warmup", "2", "--exchange", exchange], env, 900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     lines = r.stdout.splitlines()
@@ -150,12 +147,28 @@ def _free_port():
     return port
 
 
+RENDEZVOUS_TROUBLE = ("EADDRINUSE", "Address already in use", "address already in use", "RendezvousConnectionError", "RendezvousTimeoutError", "DistNetworkError",
+                      "failed to bind", "Connection refused")
+
+
+def _run_driver(make_cmd, env, timeout):
+    """Run a torch.distributed.run command; a failure of the LAUNCHER's own rendezvous (the port picked a moment ago taken by somebody else: seen once in ~30
+    suite passes) is not what these tests are about -- such a run is repeated on a fresh port, twice at most, and reported if it persists."""
+    r = None
+    for attempt in range(3):
+        r = subprocess.run(make_cmd(_free_port()), cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or not any(t in r.stderr for t in RENDEZVOUS_TROUBLE) or "[bench]" in r.stderr:
+            break
+        print(f"[test] launcher rendezvous trouble, attempt {attempt + 1}:\n{r.stderr[-1500:]}", file=sys.stderr)
+    return r
+
+
 @pytest.mark.parametrize("n", [2, 4, 8])
 def test_the_drivers_scaling_command_runs_to_one_json_line(n):
     """`--steps 20 --warmup 5`, everything else default: the metric's config (C3: 32^3 x 32^3, 100 k particles, 1920 x 1080) in N slabs, one process
     per rank.  ONE JSON line on stdout; N RCCL ranks; per-rank figures from every process; the sharded frame = the 1-GPU frame rendered on rank 0."""
     _build_mp_shim()
-    r = subprocess.run(_driver_command(n, _free_port()), cwd=ROOT, env=_driver_env(), capture_output=True, text=True, timeout=1200)
+    r = _run_driver(lambda port: _driver_command(n, port), _driver_env(), 1200)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-3000:]
@@ -179,9 +192,13 @@ def test_a_rank_that_dies_mid_run_ends_the_job_nonzero_instead_of_hanging():
     and no JSON line may be printed."""
     import time
     _build_mp_shim()
-    t0 = time.time()
-    r = subprocess.run(_driver_command(4, _free_port(), steps=10, warmup=3), cwd=ROOT,
-                       env=_driver_env(VPFX_BENCH_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=600)
+    r = None
+    for attempt in range(2):        # (a job that failed BEFORE the hook -- launcher trouble, see _run_driver -- says nothing about the hook: once more)
+        t0 = time.time()
+        r = _run_driver(lambda port: _driver_command(4, port, steps=10, warmup=3), _driver_env(VPFX_BENCH_TEST_FAIL_RANK="1"), 600)
+        if "TEST HOOK: rank 1 leaves the job" in r.stderr:
+            break
+        print(f"[test] the job ended without reaching the hook (rc {r.returncode}), attempt {attempt + 1}:\n{r.stderr[-3000:]}", file=sys.stderr)
     # (the stand-in's time-out stays at its 120 s: with 20 s a slow start of rank 0 -- it renders the 1-GPU reference frame before it joins the
     #  communicator -- once made the OTHER ranks give up first, and the job failed without ever reaching the hook; torchrun ends the survivors as soon as
     #  rank 1 is gone, so the test does not wait for the time-out)
@@ -198,8 +215,7 @@ def test_config5_shape_through_the_drivers_command_at_eight_ranks():
     and cannot share one 288-GB test GPU, so the grid is one eighth of config 5's (32^3 metavoxels, 125 k particles: 'C5e'); the full grid's sharded parity is
     tests/test_gpu_large_configs.py::test_config5_through_the_fanout_slab_by_slab."""
     _build_mp_shim()
-    cmd = _driver_command(8, _free_port(), steps=4, warmup=3) + ["--config", "C5e"]
-    r = subprocess.run(cmd, cwd=ROOT, env=_driver_env(), capture_output=True, text=True, timeout=1500)
+    r = _run_driver(lambda port: _driver_command(8, port, steps=4, warmup=3) + ["--config", "C5e"], _driver_env(), 1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-3000:]
