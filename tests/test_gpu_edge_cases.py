@@ -589,6 +589,69 @@ def test_occluder_cylinders_and_ellipsoids_produce_both_depth_inputs_on_the_gpu(
     np.testing.assert_array_equal(g.render_light_depth(), d_box)          # a refused call leaves the previous set in place
 
 
+def test_depth_maps_rendered_from_the_solids_are_reused_only_while_they_are_valid():
+    """Round 6: the eye depth / light depth map rendered from the solids stay in the context while camera, frame and solids are what they were rendered
+    for.  Every step of a sequence that changes one of those (or overwrites a buffer with a caller's map) must give, bit for bit, the frame a FRESH
+    context gives."""
+    sc = S.make_scene("T1")
+    L = np.asarray(sc.light_to_world, dtype=np.float64).reshape(4, 4).T
+    A = [S.make_solid(abi.VP_OCC_CYLINDER, (0.5, 0.0, -2.0), (1.0, 4.0, 1.0)), S.make_box((0.0, -6.0, 0.0), (40.0, 0.5, 40.0))]
+    B = [S.make_solid(abi.VP_OCC_ELLIPSOID, (-1.0, 1.0, -3.0), (2.0, 1.0, 1.5)), S.make_box((3.0, 0.0, 0.0), (0.5, 5.0, 5.0))]
+    cams = [(-1.5, 0.9, -14.0), (6.0, 3.0, -12.0)]
+
+    def fresh(solids, cam_pos, scene_depth=None, light_pos=None):
+        s2 = S.make_scene("T1")
+        s2.set_camera(cam_pos)
+        if light_pos is not None:
+            s2.light_to_world = light_pos
+        e = E.Engine(s2.config())
+        e.set_frame(s2.light_to_world, s2.grid_center)
+        e.set_occluders(solids)
+        e.bin(s2.particles, s2.layout, s2.psys_local_to_world)
+        e.fill(s2.fill_params())
+        rp = s2.raymarch_params()
+        if scene_depth is not None:
+            rp.scene_depth = scene_depth.ctypes.data_as(abi.c_float_p)
+        img, lm = e.raymarch(s2.camera(), rp), e.read_lightmap()
+        e.close()
+        return img, lm
+
+    g = E.Engine(sc.config())
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.set_occluders(A)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+
+    def frame(cam_pos, scene_depth=None):
+        sc.set_camera(cam_pos)
+        g.fill(sc.fill_params())
+        rp = sc.raymarch_params()
+        if scene_depth is not None:
+            rp.scene_depth = scene_depth.ctypes.data_as(abi.c_float_p)
+        return g.raymarch(sc.camera(), rp), g.read_lightmap()
+
+    def same(a, b):
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    ref = fresh(A, cams[0])
+    assert ref[0][..., 3].max() > 0.05 and (ref[1] < 1).any()
+    same(frame(cams[0]), ref)
+    same(frame(cams[0]), ref)                                   # both maps reused
+    same(frame(cams[1]), fresh(A, cams[1]))                      # the camera moved: eye depth rendered again
+    g.set_occluders(B)
+    same(frame(cams[1]), fresh(B, cams[1]))                      # the solids changed: both maps rendered again
+    wall = np.full((sc.height, sc.width), 3.0e38, dtype=np.float32); wall[:, : sc.width // 2] = 9.0
+    same(frame(cams[1], wall), fresh(B, cams[1], wall))          # a caller's depth buffer overwrites the rendered one ...
+    same(frame(cams[1]), fresh(B, cams[1]))                      # ... and is not mistaken for it afterwards
+    # the light turns: the light depth map belongs to the frame it was rendered for
+    L2 = S.to_colmajor16(S.trs((0.0, 0.0, -44.34), S.quat_to_matrix((0.30, 0.10, 0.0, 0.9487))))
+    sc.light_to_world = L2
+    g.set_frame(sc.light_to_world, sc.grid_center)
+    g.bin(sc.particles, sc.layout, sc.psys_local_to_world)
+    same(frame(cams[1]), fresh(B, cams[1], light_pos=L2))
+    g.set_occluders([])
+    same(frame(cams[1]), fresh([], cams[1], light_pos=L2))       # no solids: no occlusion (the stale buffers are not consulted)
+    g.close()
+
+
 def E_free_alpha(sc):
     g = E.Engine(sc.config())
     g.set_frame(sc.light_to_world, sc.grid_center)

@@ -142,15 +142,30 @@ int stage_fill_inputs(vp_ctx* c, const vp_fill_params* p)
         VP_HIP(hipMemcpyAsync(c->d_depthmap, p->light_depth_map, lightmap_elems(c) * sizeof(float), hipMemcpyHostToDevice, c->stream));
         { int rcs = stream_sync(c); if (rcs) return rcs; }
         c->have_depthmap = true;
+        c->light_depth_gen = 0;                                 // the buffer holds the caller's map now
     } else if (c->n_occluders > 0) {
-        // no map given but occluder boxes are set: render the light depth map on the GPU (VPR.cs:184)
-        if (!c->d_depthmap) { int rc = dev_alloc(c, &c->d_depthmap, lightmap_elems(c)); if (rc) return rc; }
-        int rc = launch_light_depth(c, p->light_near, p->light_far, p->light_cam_distance, c->d_depthmap); if (rc) return rc;
+        // no map given but occluder solids are set: render the light depth map on the GPU (VPR.cs:184) -- unless the buffer already holds exactly that
+        if (!c->d_depthmap) { int rc = dev_alloc(c, &c->d_depthmap, lightmap_elems(c)); if (rc) return rc; c->light_depth_gen = 0; }
+        const float planes[3] = {p->light_near, p->light_far, p->light_cam_distance};
+        if (c->light_depth_gen != c->occl_gen || c->light_depth_frame != c->frame_gen || memcmp(planes, c->light_depth_planes, sizeof planes) != 0) {
+            int rc = launch_light_depth(c, p->light_near, p->light_far, p->light_cam_distance, c->d_depthmap); if (rc) return rc;
+            c->light_depth_gen = c->occl_gen; c->light_depth_frame = c->frame_gen; memcpy(c->light_depth_planes, planes, sizeof planes);
+        }
         c->have_depthmap = true;
     } else {
         c->have_depthmap = false;                               // NULL = no occluders (depth 1.0 everywhere)
     }
     hl_build_fill_consts(c, p);
+    return VP_OK;
+}
+
+// the eye depth rendered from the solids: once per (camera, solids); see vp_ctx::eye_depth_gen
+int ensure_eye_depth(vp_ctx* c, const vp_camera* cam)
+{
+    if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; c->eye_depth_gen = 0; }
+    if (c->eye_depth_gen == c->occl_gen && memcmp(cam, &c->eye_depth_cam, sizeof *cam) == 0) return VP_OK;
+    int rc = launch_scene_depth(c, cam, c->d_scene_depth); if (rc) return rc;
+    c->eye_depth_gen = c->occl_gen; c->eye_depth_cam = *cam;
     return VP_OK;
 }
 
@@ -175,10 +190,10 @@ int stage_raymarch(vp_ctx* c, const vp_camera* cam, const vp_raymarch_params* rp
         if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
         VP_HIP(hipMemcpyAsync(c->d_scene_depth, rp->scene_depth, (size_t)c->cfg.width * c->cfg.height * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
+        c->eye_depth_gen = 0;                                   // the buffer holds the caller's depth now
     } else if (c->n_occluders > 0) {
-        // no depth buffer given but occluder boxes are set: render the eye depth on the GPU (VPR.cs:204)
-        if (!c->d_scene_depth) { int rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
-        int rc = launch_scene_depth(c, cam, c->d_scene_depth); if (rc) return rc;
+        // no depth buffer given but occluder solids are set: render the eye depth on the GPU (VPR.cs:204) -- unless the buffer already holds it for this camera
+        int rc = ensure_eye_depth(c, cam); if (rc) return rc;
     }
     // scene_depth is pageable: the async copy above has already consumed it on return
     return VP_OK;
@@ -404,6 +419,7 @@ VP_EXPORT int vp_set_frame(vp_ctx* c, const float light_to_world[16], const floa
     { int rcs = stream_sync(c); if (rcs) return rcs; }
     c->have_frame = true;
     c->binned = c->filled = c->local_done = false;
+    if (++c->frame_gen == 0) c->frame_gen = 1;
     return VP_OK;
 }
 
@@ -577,10 +593,10 @@ VP_EXPORT int vp_render_metavoxel(vp_ctx* c, const vp_camera* cam, const vp_raym
         keep = c->d_scene_depth;
         VP_HIP(hipMemcpyAsync(c->d_scene_depth, rp->scene_depth, (size_t)c->cfg.width * c->cfg.height * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
+        c->eye_depth_gen = 0;
     } else if (c->n_occluders > 0) {
-        if (!c->d_scene_depth) { rc = dev_alloc(c, &c->d_scene_depth, (size_t)c->cfg.width * c->cfg.height); if (rc) return rc; }
+        rc = ensure_eye_depth(c, cam); if (rc) return rc;
         keep = c->d_scene_depth;
-        rc = launch_scene_depth(c, cam, c->d_scene_depth); if (rc) return rc;
     } else {
         c->d_scene_depth = nullptr;
     }
@@ -829,6 +845,7 @@ VP_EXPORT int vp_set_occluders2(vp_ctx* c, const vp_occluder* solids, int32_t n)
         { int rcs = stream_sync(c); if (rcs) return rcs; }
     }
     c->n_occluders = n;
+    if (++c->occl_gen == 0) c->occl_gen = 1;
     return VP_OK;
 }
 

@@ -182,6 +182,12 @@ struct vp_ctx {
     // occluder solids (scene-occlusion inputs produced on the GPU)
     vp_occluder* d_occluders = nullptr;
     int n_occluders = 0, occluders_cap = 0;
+    // What d_scene_depth / d_depthmap hold when they were RENDERED from the solids (round 6): the eye depth is a function of the camera and the solids,
+    // the light depth map of the frame (light, grid centre), the solids and the light camera's planes -- a static camera / light does not pay the render
+    // again (the reference's scene: 1 of 2 launches per frame).  Generation 0 = nothing rendered (or the buffer was overwritten by a caller's map).
+    unsigned occl_gen = 1, frame_gen = 1;                      // bumped by vp_set_occluders2 / vp_set_frame
+    unsigned eye_depth_gen = 0; vp_camera eye_depth_cam{};
+    unsigned light_depth_gen = 0, light_depth_frame = 0; float light_depth_planes[3] = {0.f, 0.f, 0.f};
 
     // raymarch
     float4* d_mvtrans = nullptr;  // [brick_cap] per-brick translation column of _CameraToMetavoxel
