@@ -332,7 +332,10 @@ int  vp_composite_device(vp_ctx* ctx, const void* d_particles_rgba, void* d_scen
 int  vp_set_occluders(vp_ctx* ctx, const vp_obb* boxes, int32_t n);
 /* ABI 6: the same with typed solids (boxes, capped cylinders, ellipsoids); vp_set_occluders(boxes) == vp_set_occluders2 with
  * type = VP_OCC_BOX.  Both depth inputs take, per ray, the nearest BACK face under the light camera (Cull Front) and the nearest front
- * face under the main camera, exactly as for boxes.  An unknown type or a half_extent <= 0 is VP_ERR_BAD_ARG. */
+ * face under the main camera, exactly as for boxes.  An unknown type or a half_extent <= 0 is VP_ERR_BAD_ARG.
+ * A map rendered from the solids is kept in the context and reused while what it depends on is unchanged (eye depth: the vp_camera and the
+ * solids; light depth map: vp_set_frame's arguments, the solids and light_near / light_far / light_cam_distance); passing a map of your own
+ * replaces it. */
 int  vp_set_occluders2(vp_ctx* ctx, const vp_occluder* solids, int32_t n);
 /* Parity probes: render and read back the two maps. */
 int  vp_render_light_depth(vp_ctx* ctx, float light_near, float light_far, float light_cam_distance, float* out /* [(Ny*nv)][(Nx*nv)] */);
